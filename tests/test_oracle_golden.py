@@ -1,0 +1,85 @@
+"""The CPU oracle against the golden vectors recorded from the real reference.
+
+Pins oracle/monosdf_oracle.py (and the hash-grid *wiring*) to the reference's own
+outputs: tests/golden/*.npz were written by oracle/make_golden.py importing
+/root/reference on CPU.  fp32; tolerance 2e-4 relative to each tensor's max
+(the sampler's inverse CDF amplifies last-bit differences in cumsum).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import monosdf_oracle as mo
+from oracle import config, synth
+from helpers import ALL_CASES, Case, digest, rel_err
+
+TOL = 2e-4
+
+
+@pytest.mark.parametrize('name', ALL_CASES)
+def test_forward_and_grads_match_reference(name):
+    c = Case(name)
+    state = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in c.state.items()}
+    trace = {}
+    out = mo.render(state, c.conf, c.inputs, c.indices, c.pixel, c.training, c.noise)
+    assert set(out) == set(c.out)
+    for k, ref in c.out.items():
+        assert out[k].shape == ref.shape, k
+        assert rel_err(out[k], ref) < TOL, (k, rel_err(out[k], ref))
+    if c.grads or c.gdig:
+        loss = mo.probe_loss(out)
+        assert abs(loss.item() - c.loss) < 1e-5 * max(1.0, abs(c.loss))
+        names = list(c.grads) + list(c.gdig)
+        grads = torch.autograd.grad(loss, [state[n] for n in names], allow_unused=True)
+        for n, g in zip(names, grads):
+            assert g is not None, n
+            if n in c.grads:
+                assert rel_err(g, c.grads[n]) < 5e-4, (n, rel_err(g, c.grads[n]))
+            else:
+                d, ref = digest(g), c.gdig[n].double()
+                scale = ref[1] / max(1, g.numel()) + 1e-12       # mean |g|
+                assert abs(d[0] - ref[0]) < 5e-4 * ref[1] + 1e-9, n
+                assert ((d[3:] - ref[3:]).abs().max() < 5e-2 * scale * 16 + 5e-4 * ref[3:].abs().max()), n
+
+
+def test_sampler_round_counts():
+    for name in ['mlp_w64_eval', 'mlp_w64_eval_sharp', 'mlp_w64_eval_vsharp', 'mlp_w64_eval_maxit']:
+        c = Case(name)
+        trace = {}
+        rays = c.inputs
+        mo.error_bound_sampler(c.state, c.conf, rays['ray_dirs'], rays['ray_cam_loc'], False, None,
+                               trace=trace)
+        assert trace['rounds'] == c.rounds
+
+
+def test_stage_vectors(golden_dir):
+    z = np.load(golden_dir + '/stages.npz')
+    t = lambda k: torch.from_numpy(z[k])
+    conf = config.mlp_config(64, 8)
+    state = synth.make_state(conf, seed=3, jitter=0.3)
+    zz, _, far = mo.uniform_z(conf, t('uni.d'), t('uni.o'), 128)
+    assert torch.equal(zz, t('uni.z_eval')) and torch.equal(far, t('uni.far'))
+    zt, _, _ = mo.uniform_z(conf, t('uni.d'), t('uni.o'), 128, t('uni.jitter'))
+    assert torch.allclose(zt, t('uni.z_train'), rtol=0, atol=1e-6)
+    near, far = mo.far_from_cube(t('cube.o'), t('cube.d'), 1.1, 0.0, mo.sampler_far(conf))
+    assert torch.equal(near, t('cube.near')) and torch.equal(far, t('cube.far'))
+    s, b = t('dens.sdf'), t('dens.beta')
+    assert torch.allclose(mo.laplace_density(s, torch.tensor(0.1 + 1e-4)), t('dens.scalar'), rtol=1e-6, atol=1e-6)
+    assert torch.allclose(mo.laplace_density(s, b), t('dens.perray'), rtol=1e-6, atol=1e-6)
+    zq = t('eb.z')
+    eb = mo.error_bound(b, s, zq[:, 1:] - zq[:, :-1], t('eb.dstar'))
+    assert torch.allclose(eb, t('eb.out'), rtol=1e-5, atol=1e-7)
+    st01 = dict(state)
+    st01['density.beta'] = torch.tensor(0.1)
+    w = mo.volume_rendering(st01, conf, zq, s.reshape(-1, 1))
+    assert torch.allclose(w, t('vr.weights'), rtol=1e-5, atol=1e-7)
+    assert torch.equal(mo.positional_encoding(t('pe.x'), 6), t('pe.out6'))
+    assert torch.equal(mo.positional_encoding(t('pe.x'), 4), t('pe.out4'))
+    pts = t('net.pts')
+    sdf, feat, grad = mo.get_outputs(state, conf, pts)
+    assert rel_err(sdf, t('net.sdf')) < 1e-5 and rel_err(feat, t('net.feat')) < 1e-5
+    assert rel_err(grad, t('net.grad')) < 1e-5
+    assert rel_err(mo.get_sdf_vals(state, conf, pts), t('net.sdf_vals')) < 1e-5
+    assert rel_err(mo.gradient_sdf(state, conf, pts), t('net.grad_unclamped')) < 1e-5
+    rgb = mo.color_network(state, conf, pts, t('net.grad'), t('col.dirs'), t('net.feat'))
+    assert rel_err(rgb, t('col.rgb')) < 1e-5
