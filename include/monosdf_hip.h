@@ -1,0 +1,228 @@
+/* C ABI of libmonosdf_hip.so -- the gfx950 (MI355X) implementation of MonoSDF's SDF
+ * volume-rendering hot path.  Plain C: raw DEVICE pointers, sizes, an explicit
+ * hipStream_t passed as void*; every function returns 0 on success (see MSDF_* codes).
+ * Callers own every buffer; nothing here allocates, frees or synchronises.
+ *
+ * What each entry point replaces in the reference (paths relative to /root/reference/code):
+ *
+ *   msdf_hash_encode_forward / _backward / _second_backward
+ *       the pybind11 module `_hash_encoder` (hashencoder/src/bindings.cpp:5-8,
+ *       hashencoder/src/hashencoder.h:13-15): same argument order and meaning, tensors
+ *       replaced by device pointers, plus the stream the reference never passed.
+ *   msdf_pack_weights, msdf_sdf_forward, msdf_sdf_fwd_grad, msdf_sdf_backward
+ *       ImplicitNetwork / ImplicitNetworkGrid .forward / .get_sdf_vals / .get_outputs /
+ *       .gradient_sdf and their autograd double backward (model/network.py:79-137, 247-309).
+ *   msdf_color_forward, msdf_color_backward
+ *       RenderingNetwork.forward and its backward (model/network.py:389-470).
+ *   msdf_wgrad, msdf_reduce
+ *       the dW / db `mm` + `sum` nodes autograd emits for those networks
+ *       (implied by loss.backward(), training/monosdf_train.py:431).
+ *   msdf_composite_forward, msdf_composite_backward
+ *       LaplaceDensity (model/density.py:21-30), MonoSDFNetwork.volume_rendering and the
+ *       composites (model/network.py:552-562, 603-605, 626-640) and their backward.
+ *   msdf_sampler_* (see below)
+ *       ErrorBoundSampler.get_z_vals / UniformSampler.get_z_vals (model/ray_sampler.py:48-83, 110-272).
+ */
+#ifndef MONOSDF_HIP_H
+#define MONOSDF_HIP_H
+
+#include <stdint.h>
+#include "monosdf_plan.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSDF_OK 0
+#define MSDF_ERR_ARG 1
+#define MSDF_ERR_LAUNCH 2
+#define MSDF_ERR_UNSUPPORTED 3
+
+#define MSDF_ABI_VERSION 1
+int msdf_abi_version(void);
+
+/* ---- hash grid (reference: hashencoder/src/hashencoder.h:13-15) ---- */
+int msdf_hash_encode_forward(const float* inputs, const float* embeddings, const int* offsets, float* outputs,
+                             uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                             int calc_grad_inputs, float* dy_dx, void* stream);
+int msdf_hash_encode_backward(const float* grad, const float* inputs, const float* embeddings, const int* offsets,
+                              float* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                              uint32_t H, int calc_grad_inputs, const float* dy_dx, float* grad_inputs,
+                              void* stream);
+int msdf_hash_encode_second_backward(const float* grad, const float* inputs, const float* embeddings,
+                                     const int* offsets, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                     uint32_t H, int calc_grad_inputs, const float* dy_dx,
+                                     const float* grad_grad_inputs, float* grad_grad, float* grad2_embeddings,
+                                     void* stream);
+
+/* ---- fused MLPs ---- */
+int msdf_pack_weights(const msdf_plan_t* plan, const msdf_packrule_t* rules_dev, const int* maps_dev,
+                      const float* flat_w, const float* flat_b, float* wpack, float* bpack, void* stream);
+
+int msdf_sdf_forward(const msdf_plan_t* plan, const float* wpack, const float* bpack, const float* x,
+                     const float* aux, int P, float clamp_radius, float sphere_scale, float* sdf, void* stream);
+
+typedef struct {
+  const float* wpack;
+  const float* bpack;
+  const float* x;          /* [P,3] */
+  const float* aux;        /* [P, 16*aux_tiles] or NULL */
+  int32_t P, P_pad;        /* P_pad = P rounded up to 64 (workspace rows) */
+  int32_t n_clamp;         /* points [0,n_clamp) get the bounding-sphere clamp */
+  int32_t n_feat;          /* points [0,n_feat) need the feature vector (multiple of 16 or == P) */
+  float clamp_radius, sphere_scale;
+  float* sdf;              /* [P] */
+  float* feat;             /* [n_feat, 16*feat_tiles] */
+  float* nrm;              /* [P,3] */
+  float* r_aux;            /* [P, 16*aux_tiles] or NULL */
+  unsigned char* clamped;  /* [P] */
+  float* H;                /* [hsum * P_pad] */
+  float* PM;               /* [hsum * P_pad] */
+  float* IN0;              /* [P_pad, 16*(e_tiles+aux_tiles)] */
+  int32_t save;
+  int32_t pad_;
+} msdf_fg_args_t;
+int msdf_sdf_fwd_grad(const msdf_plan_t* plan, const msdf_fg_args_t* args, void* stream);
+
+typedef struct {
+  const float* wpack;
+  const float* bpack;
+  const float* x;
+  int32_t P, P_pad;
+  int32_t n_feat;
+  int32_t pad_;
+  const float* g_sdf;      /* [P] or NULL */
+  const float* g_feat;     /* [n_feat, 16*feat_tiles] or NULL */
+  const float* g_nrm;      /* [P,3] or NULL */
+  const float* g_raux;     /* [P, 16*aux_tiles] or NULL */
+  const unsigned char* clamped;
+  const float* H;
+  const float* PM;
+  float* QB;               /* [qsum * P_pad] */
+  float* T;                /* [hsum * P_pad] */
+  float* AB;               /* [absum * P_pad] */
+  float* GSDF;             /* [P_pad] */
+  float* QLAST;            /* [P_pad, 16*kt_last] */
+  float* g_aux;            /* [P, 16*aux_tiles] or NULL */
+} msdf_bw_args_t;
+int msdf_sdf_backward(const msdf_plan_t* plan, const msdf_bw_args_t* args, void* stream);
+
+typedef struct {
+  const float* wpack;
+  const float* bpack;
+  const float* x;          /* [P,3] */
+  const float* dirs;       /* [P/spr,3] */
+  const float* nrm;        /* [P,3] */
+  const float* feat;       /* [P, 16*feat_tiles] */
+  const float* code;       /* [P/spr, 16*aux_tiles] or NULL */
+  int32_t P, P_pad;
+  int32_t spr;             /* samples per ray */
+  int32_t save;
+  float* rgb;              /* [P,3] */
+  float* H;                /* [n_hidden][P_pad][16*hid_tiles] */
+  float* MISC;             /* [P_pad, 16*misc_tiles] */
+} msdf_color_fwd_args_t;
+int msdf_color_forward(const msdf_plan_t* plan, const msdf_color_fwd_args_t* args, void* stream);
+
+typedef struct {
+  const float* wpack;
+  const float* bpack;
+  const float* rgb;
+  const float* g_rgb;
+  int32_t P, P_pad;
+  const float* H;
+  float* AB;               /* [absum * P_pad] */
+  float* g_feat;           /* [P, 16*feat_tiles] */
+  float* g_misc;           /* [P, 16*misc_tiles] */
+} msdf_color_bwd_args_t;
+int msdf_color_backward(const msdf_plan_t* plan, const msdf_color_bwd_args_t* args, void* stream);
+
+int msdf_wgrad(const msdf_wgrad_item_t* items_dev, int n_items, const float* workspace, float* partials,
+               int P_pad, int n_splits, void* stream);
+int msdf_reduce(const msdf_reduce_rule_t* rules_dev, int n_rules, const int* maps_dev, const float* partials,
+                float* dst, void* stream);
+
+/* ---- compositor ---- */
+typedef struct {
+  const float* z;            /* [N,S] */
+  const float* sdf;          /* [N,S] */
+  const float* rgb;          /* [N,S,3] */
+  const float* nrm;          /* [N,S,3] */
+  const float* beta;         /* [1] = |beta| + beta_min */
+  const float* depth_scale;  /* [N] */
+  int32_t N, S;
+  int32_t white_bkgd;
+  float bg0, bg1, bg2;
+  float* weights;            /* [N,S] */
+  float* rgb_values;         /* [N,3] */
+  float* depth_values;       /* [N] */
+  float* normal_map;         /* [N,3] */
+  float* wsum;               /* [N] */
+} msdf_composite_args_t;
+int msdf_composite_forward(const msdf_composite_args_t* args, void* stream);
+
+typedef struct {
+  const float* z;
+  const float* sdf;
+  const float* rgb;
+  const float* nrm;
+  const float* beta;
+  const float* depth_scale;
+  const float* weights;
+  const float* wsum;
+  const float* depth_values;
+  const float* g_rgb_values;  /* [N,3] or NULL */
+  const float* g_depth;       /* [N] or NULL */
+  const float* g_normal;      /* [N,3] or NULL */
+  const float* g_weights;     /* [N,S] or NULL */
+  int32_t N, S;
+  int32_t white_bkgd;
+  float bg0, bg1, bg2;
+  float* g_sdf;               /* [N,S] */
+  float* g_rgb;               /* [N,S,3] */
+  float* g_nrm;               /* [N,S,3] */
+  float* g_beta_part;         /* [N] */
+} msdf_composite_bwd_args_t;
+int msdf_composite_backward(const msdf_composite_bwd_args_t* args, void* stream);
+
+/* ---- error-bounded sampler (reference: model/ray_sampler.py:48-83, 110-272) ---- */
+typedef struct {
+  const float* ray_o;        /* [N,3] */
+  const float* ray_d;        /* [N,3] */
+  int32_t N;
+  int32_t M;                 /* current number of sorted samples per ray */
+  int32_t m_max;             /* row pitch of z / sdf (>= n_eval * max_rounds) */
+  int32_t n_eval, n_final, n_extra;
+  int32_t round_idx, max_rounds;
+  int32_t training;          /* 1: final u from u_final, 0: linspace */
+  int32_t beta_iters;
+  float near, far, bound;    /* sampler near / far clip, cube half-size (scene_bounding_sphere) */
+  float eps, add_tiny;
+  float lemma;               /* 1 / (4 log(1 + eps)) */
+  const float* beta0;        /* [1] device: |beta| + beta_min */
+  float* z;                  /* [N, m_max] sorted sample distances */
+  float* sdf;                /* [N, m_max] sdf at those samples */
+  float* new_z;              /* [N, n_eval] samples added by the last round */
+  const float* new_sdf;      /* [N, n_eval] their sdf (from msdf_sdf_forward) */
+  int32_t* new_pos;          /* [N, n_eval] their positions in z */
+  float* pts;                /* [N * n_eval, 3] their 3-D points */
+  float* beta;               /* [N] */
+  uint32_t* flag;            /* [2] for this round: max beta bits, decision (1 = another round) */
+  const float* jitter;       /* [N, n_eval] or NULL (eval) */
+  const float* u_final;      /* [N, n_final] or NULL */
+  float* final_z;            /* [N, n_final] */
+  const int64_t* extra_idx;  /* [n_extra] columns of z to add to the final set */
+  const int64_t* eik_idx;    /* [N] or NULL */
+  float* z_out;              /* [N, n_final + n_extra + 2] */
+  float* z_eik;              /* [N] or NULL */
+  float* pts_out;            /* [N * S, 3] or NULL */
+} msdf_sampler_args_t;
+int msdf_sampler_init(const msdf_sampler_args_t* args, void* stream);
+int msdf_sampler_beta(const msdf_sampler_args_t* args, void* stream);
+int msdf_sampler_resample(const msdf_sampler_args_t* args, void* stream);
+int msdf_sampler_finish(const msdf_sampler_args_t* args, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

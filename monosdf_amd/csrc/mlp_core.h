@@ -1,0 +1,276 @@
+// Register-resident MLP core for gfx950 (wave64, fp32-input MFMA).
+//
+// One wave owns a tile of 16 points.  An activation vector of up to 272 slots
+// is held as 17 float4 "tiles": lane l = (point p = l & 15, quarter q = l >> 4),
+// tile t, component r  <->  slot 16 t + 4 q + r of point p.  That is exactly the
+// C/D layout of v_mfma_f32_16x16x4_f32 computing D[out][pt] = W[out][k] * act[k][pt]
+// (col = lane & 15 = point, row = 4 (lane >> 4) + reg), and at the same time its
+// B-operand layout for the NEXT layer (B[k = lane >> 4][pt = lane & 15]) with the
+// k index permuted -- the permutation is absorbed by packing the weights in
+// "fragment order": for every (out tile ot, k tile kt) a 1 KB block whose float4 of
+// lane l holds W[16 ot + (l & 15)][16 kt + 4 (l >> 4) + 0..3].  Activations never
+// leave registers between layers; weights stream HBM/L2 -> LDS (linear copy of
+// the packed image, LDS-DMA) -> one conflict-free ds_read_b128 per 4 MFMAs.
+//
+// A workgroup is 4 waves (64 points); the 4 waves share every weight chunk.
+#pragma once
+#include "common.h"
+#include "../../include/monosdf_plan.h"
+
+#ifndef MSDF_USE_GLDS
+#define MSDF_USE_GLDS 1   // 1: global_load_lds (LDS-DMA) staging, 0: register staging
+#endif
+
+#define MT MSDF_MAX_TILES   // 17
+#define MLP_THREADS 256
+#define MLP_PTS_PER_WAVE 16
+#define MLP_PTS_PER_WG 64
+#define CHUNK_OT 2                       // out tiles per LDS chunk
+#define LDS_BUF_F4 (CHUNK_OT * MT * 64)  // float4 per LDS buffer (34 KB)
+#define MLP_LDS_BYTES (2 * LDS_BUF_F4 * 16)
+
+#define V4ZERO ((v4f){0.f, 0.f, 0.f, 0.f})
+
+__device__ __forceinline__ v4f mfma4(const v4f a, const v4f b, v4f c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, c, 0, 0, 0);
+  return c;
+}
+
+// Copy one weight chunk (n_f4 float4, a multiple of 64) global -> LDS, linear image.
+#if MSDF_USE_GLDS
+template <int PIECES_MAX>
+__device__ __forceinline__ void chunk_issue(const v4f* __restrict__ src, v4f* dst, const int n_f4) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: keeps the branch below uniform
+  const int lane = threadIdx.x & 63;
+  const int pieces = n_f4 >> 6;   // 1 KB pieces, one wave-instruction each
+#pragma unroll
+  for (int i = 0; i < (PIECES_MAX + 3) / 4; ++i) {
+    const int piece = wave + 4 * i;
+    if (piece < pieces) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 64 + lane),
+                                       (__attribute__((address_space(3))) void*)(dst + piece * 64), 16, 0, 0);
+    }
+  }
+}
+#endif
+
+// acc[0..OT) += W * in, W given as the fragment-ordered pack [ceil2(OT)][K][64] float4.
+// KT_T > 0: K is the compile-time constant KT_T (fully unrolled, no guards);
+// KT_T == 0: K = k_rt at run time (every k tile guarded by a wave-uniform branch).
+// All 256 threads of the workgroup must call this together (it contains barriers).
+// `lds` points at 2 * LDS_BUF_F4 float4; on return every wave has passed a barrier
+// after its last LDS read, so the caller may start the next gemm immediately.
+template <int KT_T>
+__device__ __forceinline__ void gemm_tiles(v4f (&acc)[MT], const v4f (&in)[MT], const int OT, const int k_rt,
+                                           const v4f* __restrict__ wsrc, v4f* lds) {
+  constexpr bool DYN = (KT_T == 0);
+  constexpr int KMAX = DYN ? MT : KT_T;
+  const int K = DYN ? k_rt : KT_T;
+  const int ch_f4 = CHUNK_OT * K * 64;
+  const int lane = threadIdx.x & 63;
+  const int nchunks = (OT + CHUNK_OT - 1) / CHUNK_OT;
+#if MSDF_USE_GLDS
+  chunk_issue<CHUNK_OT * KMAX>(wsrc, lds, ch_f4);
+#else
+  constexpr int PER_T = (CHUNK_OT * KMAX * 64 + MLP_THREADS - 1) / MLP_THREADS;
+  const int tid = threadIdx.x;
+  v4f stage[PER_T];
+#pragma unroll
+  for (int i = 0; i < PER_T; ++i) {
+    const int idx = tid + i * MLP_THREADS;
+    if (idx < ch_f4) stage[i] = wsrc[idx];
+  }
+#pragma unroll
+  for (int i = 0; i < PER_T; ++i) {
+    const int idx = tid + i * MLP_THREADS;
+    if (idx < ch_f4) lds[idx] = stage[i];
+  }
+#endif
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < (MT + 1) / 2; ++c) {
+    if (c < nchunks) {
+      const int buf = c & 1;
+      const bool has_next = (c + 1 < nchunks);
+      if (has_next) {
+        const v4f* src = wsrc + (size_t)(c + 1) * ch_f4;
+#if MSDF_USE_GLDS
+        chunk_issue<CHUNK_OT * KMAX>(src, lds + (buf ^ 1) * LDS_BUF_F4, ch_f4);
+#else
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) {
+          const int idx = tid + i * MLP_THREADS;
+          if (idx < ch_f4) stage[i] = src[idx];
+        }
+#endif
+      }
+      const v4f* w0 = lds + buf * LDS_BUF_F4 + lane;
+      const v4f* w1 = w0 + K * 64;
+      const int o0 = 2 * c;
+      const int o1 = (2 * c + 1 < MT) ? 2 * c + 1 : 0;   // the dead pair of the last odd tile
+      if (2 * c + 1 < MT && 2 * c + 1 < OT) {
+#pragma unroll
+        for (int kt = 0; kt < KMAX; ++kt) {
+          if (!DYN || kt < K) {
+            const v4f a0 = w0[kt * 64];
+            const v4f a1 = w1[kt * 64];
+            const v4f b = in[kt];
+            v4f c0 = acc[o0], c1 = acc[o1];
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b.x, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b.y, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b.z, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b.z, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b.w, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b.w, c1, 0, 0, 0);
+            acc[o0] = c0;
+            acc[o1] = c1;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int kt = 0; kt < KMAX; ++kt) {
+          if (!DYN || kt < K) acc[o0] = mfma4(w0[kt * 64], in[kt], acc[o0]);
+        }
+      }
+#if !MSDF_USE_GLDS
+      if (has_next) {
+        v4f* dst = lds + (buf ^ 1) * LDS_BUF_F4;
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) {
+          const int idx = tid + i * MLP_THREADS;
+          if (idx < ch_f4) dst[idx] = stage[i];
+        }
+      }
+#endif
+      __syncthreads();
+    }
+  }
+}
+
+// Specialised for the K values of the 256-wide networks; anything else takes the guarded path.
+__device__ __forceinline__ void gemm_dispatch(const int kp, v4f (&acc)[MT], const v4f (&in)[MT], const int OT,
+                                              const v4f* __restrict__ wsrc, v4f* lds) {
+  switch (kp) {
+    case 3: gemm_tiles<3>(acc, in, OT, 3, wsrc, lds); break;
+    case 16: gemm_tiles<16>(acc, in, OT, 16, wsrc, lds); break;
+    case 17: gemm_tiles<17>(acc, in, OT, 17, wsrc, lds); break;
+    default: gemm_tiles<0>(acc, in, OT, kp, wsrc, lds); break;
+  }
+}
+
+__device__ __forceinline__ void zero_tiles(v4f (&a)[MT]) {
+#pragma unroll
+  for (int t = 0; t < MT; ++t) a[t] = V4ZERO;
+}
+
+// dst[base + j] = src[j] (j < n), dst[t] = 0 for t >= base + n.  `base`, `n` wave-uniform.
+__device__ __forceinline__ void place_tiles(v4f (&dst)[MT], const int base, const v4f (&src)[5], const int n) {
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    if (t >= base) {
+      v4f v = V4ZERO;
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+        if (j < n && t == base + j) v = src[j];
+      dst[t] = v;
+    }
+  }
+}
+
+// dst[j] += src[base + j] (j < n)
+__device__ __forceinline__ void gather_tiles(v4f (&dst)[5], const v4f (&src)[MT], const int base, const int n) {
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+      if (j < n && t == base + j) dst[j] += src[t];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Positional encoding in slot layout (reference: code/model/embedder.py:10-50).
+// PE index j: j < 3 -> x_j ; else m = j - 3, octave k = m / 6, (m % 6) < 3 -> sin(2^k x_c),
+// else cos(2^k x_c), c = m % 3.  A lane owns slots 16 t + 4 q + r, t < 3.
+// Stateless on purpose (recomputed where needed) to keep registers for the tiles.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void pe_slot(const int j, const int n_valid, const float x0, const float x1,
+                                        const float x2, float& val, float& dval, int& c) {
+  val = 0.f; dval = 0.f; c = 3;
+  if (j < 3) {
+    c = j;
+    val = (c == 0) ? x0 : (c == 1) ? x1 : x2;
+    dval = 1.f;
+  } else if (j < n_valid) {
+    const int m = j - 3;
+    const int k = m / 6;
+    const int w = m - 6 * k;
+    c = (w >= 3) ? w - 3 : w;
+    const float xc = (c == 0) ? x0 : (c == 1) ? x1 : x2;
+    const float f = (float)(1 << k);
+    float sn, cs;
+    sincosf(xc * f, &sn, &cs);
+    if (w < 3) { val = sn; dval = f * cs; } else { val = cs; dval = -f * sn; }
+  }
+}
+
+// e[t][r] for t < 3
+__device__ __forceinline__ void pe_values(v4f (&e)[5], const float x0, const float x1, const float x2,
+                                          const int n_freqs) {
+  const int q = lane_id() >> 4;
+  const int n_valid = 3 + 6 * n_freqs;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v, dv; int c;
+      pe_slot(16 * t + 4 * q + r, n_valid, x0, x1, x2, v, dv, c);
+      e[t][r] = v;
+    }
+  }
+}
+
+// n_c = sum_j r_j de_j [c(j) == c], reduced over the 4 quarter lanes of the point
+__device__ __forceinline__ void pe_jacobian_transpose(const v4f (&r)[5], const float x0, const float x1,
+                                                      const float x2, const int n_freqs, float& n0, float& n1,
+                                                      float& n2) {
+  const int q = lane_id() >> 4;
+  const int n_valid = 3 + 6 * n_freqs;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float v, dv; int c;
+      pe_slot(16 * t + 4 * q + k, n_valid, x0, x1, x2, v, dv, c);
+      const float w = r[t][k] * dv;
+      a0 += (c == 0) ? w : 0.f;
+      a1 += (c == 1) ? w : 0.f;
+      a2 += (c == 2) ? w : 0.f;
+    }
+  }
+  n0 = sum_over_quarters(a0);
+  n1 = sum_over_quarters(a1);
+  n2 = sum_over_quarters(a2);
+}
+
+// rbar_j = de_j * nbar_{c(j)}  for the PE tiles (t < 3)
+__device__ __forceinline__ void pe_jacobian(v4f (&rbar)[5], const float x0, const float x1, const float x2,
+                                            const int n_freqs, const float g0, const float g1, const float g2) {
+  const int q = lane_id() >> 4;
+  const int n_valid = 3 + 6 * n_freqs;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float v, dv; int c;
+      pe_slot(16 * t + 4 * q + k, n_valid, x0, x1, x2, v, dv, c);
+      const float g = (c == 0) ? g0 : (c == 1) ? g1 : (c == 2) ? g2 : 0.f;
+      rbar[t][k] = dv * g;
+    }
+  }
+}

@@ -1,0 +1,184 @@
+// Weight-gradient GEMMs for the fused MLPs: D[wx x wy] = sum over points of X[p][:]^T Y[p][:].
+//
+// The contraction runs over points (K ~ 1e5), so one workgroup keeps a whole
+// <=256x256 fp32 result in registers (8 waves x 128 accumulator VGPRs,
+// v_mfma_f32_32x32x2_f32) and streams its share of the points HBM -> LDS (LDS-DMA,
+// double buffered) -> one ds_read_b32 per operand fragment.  Each split writes a
+// partial block; msdf_reduce_kernel sums the partials in a fixed order (bitwise
+// reproducible, no float atomics) and scatters them back to the original
+// [out][in] weight layout.
+//
+// Replaces the `mm` calls autograd emits for dW in the reference's backward
+// (implied by loss.backward(), code/training/monosdf_train.py:431).
+#include "common.h"
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+#define WG_THREADS 512
+#define WG_NP 32                               // points per LDS stage
+#define WG_TILE_F (WG_NP * 256)                // floats per operand tile
+#define WG_STAGE_F (2 * WG_TILE_F + 64)        // X tile, Y tile, v[NP] (+pad)
+#define WG_LDS_BYTES (2 * WG_STAGE_F * 4)
+
+__device__ __forceinline__ void wg_issue_tile(const float* __restrict__ src, const int ld, const int w,
+                                              float* dst) {
+  // copy [WG_NP x w] (row pitch ld) into a dense LDS image, 16 B per lane, 1 KB per wave-instruction
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int w4 = w >> 2;
+  const int units = WG_NP * w4;                // float4 units, a multiple of 64 (w multiple of 16, NP = 32)
+  const int pieces = units >> 6;
+  for (int piece = wave; piece < pieces; piece += WG_THREADS / 64) {
+    const int u = piece * 64 + lane;
+    const int row = u / w4, c4 = u - row * w4;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)row * ld + 4 * c4),
+                                     (__attribute__((address_space(3))) void*)(dst + piece * 256), 16, 0, 0);
+  }
+}
+
+__global__ void __launch_bounds__(WG_THREADS, 2)
+msdf_wgrad_k(const msdf_wgrad_item_t* __restrict__ items, const float* __restrict__ ws,
+                  float* __restrict__ part, const int P_pad, const int n_splits) {
+  extern __shared__ float lds_f[];
+  const msdf_wgrad_item_t it = items[blockIdx.y];
+  const int split = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wave >> 2, wj = wave & 3;     // 2 x 4 waves: 128 rows x 64 cols each
+  const int i_base = 128 * wi, j_base = 64 * wj;
+
+  // point range of this split, in stages of WG_NP points
+  const int n_stages_total = P_pad / WG_NP;
+  const int per = (n_stages_total + n_splits - 1) / n_splits;
+  const int s_begin = split * per;
+  const int s_end = min(n_stages_total, s_begin + per);
+
+  const float* X = ws + it.x_off;
+  const float* Y = ws + it.y_off;
+  const float* V = (it.v_off >= 0) ? ws + it.v_off : nullptr;
+  const bool do_mm = it.wy > 0;
+
+  v16f acc[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  float colsum = 0.f, vrow = 0.f;
+
+  // which of this wave's tiles are inside [wx x wy]
+  bool ai[4], bj[2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) ai[a] = (i_base + 32 * a) < it.wx;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) bj[b] = (j_base + 32 * b) < it.wy;
+  const bool wave_active = do_mm && ai[0] && bj[0];
+
+  auto issue = [&](int stage, int buf) {
+    float* base = lds_f + buf * WG_STAGE_F;
+    const size_t p0 = (size_t)stage * WG_NP;
+    wg_issue_tile(X + p0 * it.x_ld, it.x_ld, it.wx, base);
+    if (do_mm) wg_issue_tile(Y + p0 * it.y_ld, it.y_ld, it.wy, base + WG_TILE_F);
+    if (V != nullptr && tid < WG_NP) base[2 * WG_TILE_F + tid] = V[p0 + tid];
+  };
+
+  if (s_begin < s_end) issue(s_begin, 0);
+  __syncthreads();
+  for (int s = s_begin; s < s_end; ++s) {
+    const int buf = (s - s_begin) & 1;
+    if (s + 1 < s_end) issue(s + 1, buf ^ 1);
+    const float* xt = lds_f + buf * WG_STAGE_F;
+    const float* yt = xt + WG_TILE_F;
+    const float* vt = xt + 2 * WG_TILE_F;
+    if (wave_active) {
+      const float* xa = xt + (lane >> 5) * it.wx + i_base + (lane & 31);
+      const float* yb = yt + (lane >> 5) * it.wy + j_base + (lane & 31);
+#pragma unroll 4
+      for (int k = 0; k < WG_NP / 2; ++k) {
+        float af[4], bf[2];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) af[a] = xa[2 * k * it.wx + 32 * a];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) bf[b] = yb[2 * k * it.wy + 32 * b];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+      }
+    }
+    if (it.colsum_off >= 0 && tid < it.wx) {
+#pragma unroll 8
+      for (int p = 0; p < WG_NP; ++p) colsum += xt[p * it.wx + tid];
+    }
+    if (it.vrow_off >= 0 && tid >= 256 && (tid - 256) < it.wy) {
+#pragma unroll 8
+      for (int p = 0; p < WG_NP; ++p) vrow += vt[p] * yt[p * it.wy + (tid - 256)];
+    }
+    __syncthreads();
+  }
+
+  // ---------------- write this split's partials ----------------
+  if (wave_active) {
+    float* out = part + it.part_off + (size_t)split * it.wx * it.wy;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        if (ai[a] && bj[b]) {
+          const int j = j_base + 32 * b + (lane & 31);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int i = i_base + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (i < it.wx && j < it.wy) out[(size_t)i * it.wy + j] = acc[a][b][r];
+          }
+        }
+      }
+    }
+  }
+  if (it.colsum_off >= 0 && tid < it.wx) part[it.colsum_off + (size_t)split * it.wx + tid] = colsum;
+  if (it.vrow_off >= 0 && tid >= 256 && (tid - 256) < it.wy)
+    part[it.vrow_off + (size_t)split * it.wy + (tid - 256)] = vrow;
+}
+
+// dst[rowmap[i]*ld + colmap[j]] = scale * sum_b PART[b][i][j]   (fixed summation order)
+__global__ void __launch_bounds__(256)
+msdf_reduce_k(const msdf_reduce_rule_t* __restrict__ rules, const int* __restrict__ maps,
+                   const float* __restrict__ part, float* __restrict__ dst) {
+  const msdf_reduce_rule_t R = rules[blockIdx.y];
+  const int n = R.wx * R.wy;
+  const float* src = part + R.part_off;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    const int i = e / R.wy, j = e - i * R.wy;
+    const int row = (R.rowmap_off >= 0) ? maps[R.rowmap_off + i] : R.fixed_row;
+    const int col = (R.colmap_off >= 0) ? maps[R.colmap_off + j] : 0;
+    if (row < 0 || col < 0) continue;
+    float s = 0.f;
+    for (int b = 0; b < R.n_blocks; ++b) s += src[(size_t)b * n + e];
+    dst[R.dst_off + (size_t)row * R.dst_ld + col] = R.scale * s;
+  }
+}
+
+extern "C" int msdf_wgrad(const msdf_wgrad_item_t* items_dev, int n_items, const float* workspace, float* partials,
+                          int P_pad, int n_splits, void* stream) {
+  if (n_items < 0 || n_splits < 1 || P_pad < 0 || (P_pad % WG_NP) != 0) return MSDF_ERR_ARG;
+  if (n_items == 0 || P_pad == 0) return MSDF_OK;
+  if (hipFuncSetAttribute((const void*)msdf_wgrad_k, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS_BYTES) !=
+      hipSuccess)
+    return MSDF_ERR_LAUNCH;
+  const dim3 grid(n_splits, n_items);
+  msdf_wgrad_k<<<grid, WG_THREADS, WG_LDS_BYTES, (hipStream_t)stream>>>(items_dev, workspace, partials, P_pad,
+                                                                         n_splits);
+  return msdf_check_launch();
+}
+
+extern "C" int msdf_reduce(const msdf_reduce_rule_t* rules_dev, int n_rules, const int* maps_dev,
+                           const float* partials, float* dst, void* stream) {
+  if (n_rules < 0) return MSDF_ERR_ARG;
+  if (n_rules == 0) return MSDF_OK;
+  const dim3 grid(64, n_rules);
+  msdf_reduce_k<<<grid, 256, 0, (hipStream_t)stream>>>(rules_dev, maps_dev, partials, dst);
+  return msdf_check_launch();
+}

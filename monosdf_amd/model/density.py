@@ -1,0 +1,29 @@
+"""SDF -> density (reference: code/model/density.py:5-30).  ``LaplaceDensity.forward`` is used by
+callers outside the fused path; inside MonoSDFNetwork.forward the density is evaluated by the
+compositor / sampler kernels from ``get_beta()``."""
+import torch
+import torch.nn as nn
+
+
+class Density(nn.Module):
+    def __init__(self, params_init={}):
+        super().__init__()
+        for p in params_init:
+            setattr(self, p, nn.Parameter(torch.tensor(params_init[p])))
+
+    def forward(self, sdf, beta=None):
+        return self.density_func(sdf, beta=beta)
+
+
+class LaplaceDensity(Density):
+    def __init__(self, params_init={}, beta_min=0.0001):
+        super().__init__(params_init=params_init)
+        self.register_buffer('beta_min', torch.tensor(beta_min), persistent=False)
+
+    def density_func(self, sdf, beta=None):
+        if beta is None:
+            beta = self.get_beta()
+        return (1 / beta) * (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() / beta))
+
+    def get_beta(self):
+        return self.beta.abs() + self.beta_min

@@ -1,0 +1,396 @@
+"""Drop-in model classes for the reference's ``model.network`` (code/model/network.py):
+ImplicitNetwork (12-137), ImplicitNetworkGrid (141-322), RenderingNetwork (325-470) and
+MonoSDFNetwork (472-640) -- same constructors, method names, output dict and state-dict keys
+(``lin{l}.weight_g / weight_v / bias``, ``encoding.embeddings / offsets``, ``density.beta``).
+
+The modules only hold parameters and orchestrate; every per-point / per-ray computation is a
+HIP kernel reached through monosdf_amd.ops (no eager-PyTorch fallback: CPU tensors raise).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops, plan as planlib
+from ..hashencoder.hashgrid import HashEncoder
+from .density import LaplaceDensity
+from .ray_sampler import ErrorBoundSampler
+
+
+class WNLinear(nn.Module):
+    """Parameter holder with the reference's old-style weight-norm names (weight_g, weight_v, bias).
+
+    The initial values are drawn exactly like ``nn.utils.weight_norm(nn.Linear(...))`` after the
+    reference's init function ran on the Linear, so a given torch seed yields the same state dict."""
+
+    def __init__(self, in_dim, out_dim, init_fn=None, weight_norm=True):
+        super().__init__()
+        lin = nn.Linear(in_dim, out_dim)          # consumes the RNG like the reference
+        if init_fn is not None:
+            init_fn(lin)
+        self.in_features, self.out_features = in_dim, out_dim
+        self.has_weight_norm = weight_norm
+        self.bias = nn.Parameter(lin.bias.data.clone())
+        if weight_norm:
+            w = lin.weight.data
+            self.weight_g = nn.Parameter(torch.norm_except_dim(w, 2, 0).clone())
+            self.weight_v = nn.Parameter(w.clone())
+        else:
+            self.weight = nn.Parameter(lin.weight.data.clone())
+
+    def effective_weight(self):
+        if self.has_weight_norm:
+            return torch._weight_norm(self.weight_v, self.weight_g, 0)
+        return self.weight
+
+
+def _flat_params(layers):
+    w = torch.cat([l.effective_weight().reshape(-1) for l in layers])
+    b = torch.cat([l.bias.reshape(-1) for l in layers])
+    return w, b
+
+
+class _FusedNet(nn.Module):
+    """Shared plumbing: lazily created device state + per-call packing of the effective weights."""
+
+    def _layers(self):
+        return [getattr(self, 'lin%d' % l) for l in range(self.num_layers - 1)]
+
+    def _fused(self, device):
+        f = getattr(self, '_fused_state', None)
+        if f is None or f.device != device:
+            f = ops.FusedMlp(self._build_plan(), device)
+            object.__setattr__(self, '_fused_state', f)
+        return f
+
+    def packed(self, device):
+        """(fused, flat_w, flat_b, wpack, bpack); reused inside MonoSDFNetwork.forward via share()."""
+        shared = getattr(self, '_shared', None)
+        if shared is not None:
+            return shared
+        fused = self._fused(device)
+        flat_w, flat_b = _flat_params(self._layers())
+        wpack, bpack = fused.pack(flat_w, flat_b)
+        return fused, flat_w, flat_b, wpack, bpack
+
+    def share(self, device):
+        object.__setattr__(self, '_shared', None)
+        object.__setattr__(self, '_shared', self.packed(device))
+
+    def unshare(self):
+        object.__setattr__(self, '_shared', None)
+
+
+def _geometric_init(l, num_layers, dims, skip_in, multires, bias, inside_outside, out_dim):
+    """The reference's geometric initialisation (network.py:51-70) as a function of the layer index."""
+    def fn(lin):
+        if l == num_layers - 2:
+            if not inside_outside:
+                torch.nn.init.normal_(lin.weight, mean=np.sqrt(np.pi) / np.sqrt(dims[l]), std=0.0001)
+                torch.nn.init.constant_(lin.bias, -bias)
+            else:
+                torch.nn.init.normal_(lin.weight, mean=-np.sqrt(np.pi) / np.sqrt(dims[l]), std=0.0001)
+                torch.nn.init.constant_(lin.bias, bias)
+        elif multires > 0 and l == 0:
+            torch.nn.init.constant_(lin.bias, 0.0)
+            torch.nn.init.constant_(lin.weight[:, 3:], 0.0)
+            torch.nn.init.normal_(lin.weight[:, :3], 0.0, np.sqrt(2) / np.sqrt(out_dim))
+        elif multires > 0 and l in skip_in:
+            torch.nn.init.constant_(lin.bias, 0.0)
+            torch.nn.init.normal_(lin.weight, 0.0, np.sqrt(2) / np.sqrt(out_dim))
+            torch.nn.init.constant_(lin.weight[:, -(dims[0] - 3):], 0.0)
+        else:
+            torch.nn.init.constant_(lin.bias, 0.0)
+            torch.nn.init.normal_(lin.weight, 0.0, np.sqrt(2) / np.sqrt(out_dim))
+    return fn
+
+
+class _SdfBase(_FusedNet):
+    """Common part of ImplicitNetwork / ImplicitNetworkGrid."""
+
+    def _make_layers(self, dims, geometric_init, bias, skip_in, weight_norm, multires, inside_outside):
+        self.num_layers = len(dims)
+        self.skip_in = tuple(skip_in)
+        self.dims = list(dims)
+        for l in range(self.num_layers - 1):
+            out_dim = dims[l + 1] - dims[0] if (l + 1) in self.skip_in else dims[l + 1]
+            init = _geometric_init(l, self.num_layers, dims, self.skip_in, multires, bias, inside_outside,
+                                   out_dim) if geometric_init else None
+            setattr(self, 'lin%d' % l, WNLinear(dims[l], out_dim, init, weight_norm))
+
+    def _build_plan(self):
+        shapes = [(l.out_features, l.in_features) for l in self._layers()]
+        return planlib.build_sdf_plan(shapes, self.skip_in, self.multires, self.aux_cols, self.aux_active,
+                                      self.feature_vector_size)
+
+    # -- one fused evaluation -------------------------------------------------------------
+    def evaluate(self, x, n_clamp, n_feat, save=None):
+        """sdf [P,1], feat [n_feat,F], d sdf/dx [P,3] for the points x; the first n_clamp points get the
+        bounding-sphere clamp, the first n_feat points get feature vectors."""
+        if save is None:
+            save = torch.is_grad_enabled()
+        x = x.detach()
+        fused, flat_w, flat_b, wpack, bpack = self.packed(x.device)
+        aux, handle = None, None
+        if self.aux_active:
+            aux, handle = self.encoding.encode_with_jacobian((x / self.divide_factor + 1.0) / 2.0)
+        radius = self.sdf_bounding_sphere if self.clamps else 0.0
+        sdf, feat, nrm, r_aux = ops.SdfMlpFunction.apply(x, aux, flat_w, flat_b, wpack, bpack, fused, int(n_clamp),
+                                                         int(n_feat), radius, self.sphere_scale, bool(save))
+        if self.aux_active:
+            # chain rule through x01 = (x / divide_factor + 1) / 2
+            nrm = nrm + self.encoding.input_gradient(handle, r_aux) * (0.5 / self.divide_factor)
+        return sdf, feat, nrm
+
+    def gradient_sdf(self, x):
+        return self.evaluate(x, 0, 0)[2]
+
+    def get_outputs(self, x):
+        P = x.shape[0]
+        return self.evaluate(x, P, P)
+
+    def _sdf_only(self, x):
+        fused, _, _, wpack, bpack = self.packed(x.device)
+        aux = None
+        if self.aux_active:
+            with torch.no_grad():
+                aux = self.encoding((x / self.divide_factor).detach(), calc_grad_inputs=False).contiguous()
+        radius = self.sdf_bounding_sphere if self.clamps else 0.0
+        return ops.sdf_forward_nograd(fused, wpack, bpack, x.detach(), aux, radius, self.sphere_scale)
+
+
+class ImplicitNetwork(_SdfBase):
+    def __init__(self, feature_vector_size, sdf_bounding_sphere, d_in, d_out, dims, geometric_init=True,
+                 bias=1.0, skip_in=(), weight_norm=True, multires=0, sphere_scale=1.0, inside_outside=False):
+        super().__init__()
+        self.sdf_bounding_sphere = sdf_bounding_sphere
+        self.sphere_scale = sphere_scale
+        self.feature_vector_size = feature_vector_size
+        self.multires = multires
+        self.aux_cols, self.aux_active, self.clamps = 0, False, True
+        dims = [d_in] + list(dims) + [d_out + feature_vector_size]
+        if multires > 0:
+            dims[0] = d_in + 2 * d_in * multires
+        self._make_layers(dims, geometric_init, bias, skip_in, weight_norm, multires, inside_outside)
+
+    def forward(self, x):
+        """[P, 1 + feature] : raw (unclamped) sdf in column 0 (reference network.py:79-96)."""
+        P = x.shape[0]
+        sdf, feat, _ = self.evaluate(x, 0, P)
+        return torch.cat([sdf, feat], 1)
+
+    def get_sdf_vals(self, x):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            P = x.shape[0]
+            return self.evaluate(x, P, 0)[0]
+        return self._sdf_only(x)
+
+
+class ImplicitNetworkGrid(_SdfBase):
+    def __init__(self, feature_vector_size, sdf_bounding_sphere, d_in, d_out, dims, geometric_init=True,
+                 bias=1.0, skip_in=(), weight_norm=True, multires=0, sphere_scale=1.0, inside_outside=False,
+                 base_size=16, end_size=2048, logmap=19, num_levels=16, level_dim=2, divide_factor=1.5,
+                 use_grid_feature=True, debug=False):
+        super().__init__()
+        self.sdf_bounding_sphere = sdf_bounding_sphere
+        self.sphere_scale = sphere_scale
+        self.feature_vector_size = feature_vector_size
+        self.multires = multires
+        self.divide_factor = divide_factor
+        self.grid_feature_dim = num_levels * level_dim
+        self.use_grid_feature = use_grid_feature
+        self.aux_cols, self.aux_active, self.clamps = self.grid_feature_dim, bool(use_grid_feature), False
+        dims = [d_in] + list(dims) + [d_out + feature_vector_size]
+        dims[0] += self.grid_feature_dim
+        self.encoding = HashEncoder(input_dim=3, num_levels=num_levels, level_dim=level_dim, per_level_scale=2,
+                                    base_resolution=base_size, log2_hashmap_size=logmap,
+                                    desired_resolution=end_size)
+        if multires > 0:
+            dims[0] += 2 * d_in * multires
+        self._make_layers(dims, geometric_init, bias, skip_in, weight_norm, multires, inside_outside)
+
+    def forward(self, x):
+        P = x.shape[0]
+        sdf, feat, _ = self.evaluate(x, 0, P)
+        return {'sdf': sdf, 'feature': feat}
+
+    def get_sdf_vals(self, x):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self.evaluate(x, 0, 0)[0]
+        return self._sdf_only(x)
+
+    def mlp_parameters(self):
+        params = []
+        for l in self._layers():
+            params += list(l.parameters())
+        return params
+
+    def grid_parameters(self):
+        return self.encoding.parameters()
+
+
+class RenderingNetwork(_FusedNet):
+    def __init__(self, feature_vector_size, mode, d_in, d_out, dims, weight_norm=True, multires_view=0,
+                 per_image_code=False, if_hdr=False, spec=False, debug=False):
+        super().__init__()
+        if spec:
+            raise NotImplementedError('monosdf_amd: the diffuse/specular split (spec=True) is outside the hot path')
+        if mode not in ('idr', 'nerf'):
+            raise NotImplementedError(mode)
+        self.mode = mode
+        self.spec = False
+        self.feature_vector_size = feature_vector_size
+        self.multires_view = multires_view
+        dims = [d_in + feature_vector_size] + list(dims) + [d_out]
+        if multires_view > 0:
+            dims[0] += 6 * multires_view
+        self.per_image_code = per_image_code
+        if per_image_code:
+            self.embeddings = nn.Parameter(torch.empty(1024, 32))
+            self.embeddings.data.uniform_(-1e-4, 1e-4)
+            dims[0] += 32
+        self.num_layers = len(dims)
+        self.if_hdr = if_hdr
+        for l in range(self.num_layers - 1):
+            setattr(self, 'lin%d' % l, WNLinear(dims[l], dims[l + 1], None, weight_norm))
+
+    def _build_plan(self):
+        shapes = [(l.out_features, l.in_features) for l in self._layers()]
+        return planlib.build_color_plan(shapes, self.mode, self.multires_view, self.feature_vector_size,
+                                        32 if self.per_image_code else 0, self.if_hdr)
+
+    def forward(self, points, normals, view_dirs, feature_vectors, indices, if_pixel_input=False,
+                samples_per_ray=None):
+        """view_dirs: one direction per point [P,3] (reference signature) or one per ray with
+        ``samples_per_ray`` given (the fused path, avoids materialising the repeat)."""
+        P = points.shape[0]
+        if samples_per_ray is None:
+            samples_per_ray, dirs = 1, view_dirs
+        else:
+            dirs = view_dirs
+        code = None
+        if self.per_image_code:
+            n_rays = P // samples_per_ray
+            if not if_pixel_input:
+                code = self.embeddings[indices].expand(n_rays, -1)
+            else:
+                code = self.embeddings[indices]
+                if code.shape[0] != n_rays:      # per-point directions: expand per sample like the reference
+                    code = code.unsqueeze(1).expand(-1, n_rays // code.shape[0], -1).flatten(0, 1)
+            code = code.contiguous()
+        fused, flat_w, flat_b, wpack, bpack = self.packed(points.device)
+        rgb = ops.ColorMlpFunction.apply(points, dirs, normals, feature_vectors, code, flat_w, flat_b, wpack, bpack,
+                                         fused, int(samples_per_ray), torch.is_grad_enabled())
+        return {'rgb': rgb}
+
+
+class MonoSDFNetwork(nn.Module):
+    def __init__(self, conf, if_hdr=False):
+        super().__init__()
+        self.feature_vector_size = conf.get_int('feature_vector_size')
+        self.scene_bounding_sphere = conf.get_float('scene_bounding_sphere', default=1.0)
+        self.white_bkgd = conf.get_bool('white_bkgd', default=False)
+        self.register_buffer('bg_color', torch.tensor(conf.get_list('bg_color', default=[1.0, 1.0, 1.0])).float(),
+                             persistent=False)
+        self.if_hdr = if_hdr
+        Grid_MLP = conf.get_bool('Grid_MLP', default=False)
+        self.Grid_MLP = Grid_MLP
+        sphere = 0.0 if self.white_bkgd else self.scene_bounding_sphere
+        cls = ImplicitNetworkGrid if Grid_MLP else ImplicitNetwork
+        self.implicit_network = cls(self.feature_vector_size, sphere, **conf.get_config('implicit_network'))
+        self.rendering_network = RenderingNetwork(self.feature_vector_size, **conf.get_config('rendering_network'),
+                                                  if_hdr=self.if_hdr)
+        self.spec = False
+        self.density = LaplaceDensity(**conf.get_config('density'))
+        self.ray_sampler = ErrorBoundSampler(self.scene_bounding_sphere, **conf.get_config('ray_sampler'))
+        self._noise = None      # tests inject the six random draws here (SURVEY.md 8(a) RNG note)
+
+    # -- rays ------------------------------------------------------------------------------
+    def _rays(self, input_dict, if_pixel_input):
+        if not if_pixel_input:
+            from ..utils import rend_util
+            uv, pose, intrinsics = input_dict['uv'], input_dict['pose'], input_dict['intrinsics']
+            ray_dirs, cam_loc = rend_util.get_camera_params(uv, pose, intrinsics)
+            eye = torch.eye(4, device=pose.device, dtype=pose.dtype)[None]
+            ray_dirs_tmp, _ = rend_util.get_camera_params(uv, eye, intrinsics)
+            cam_loc = cam_loc.unsqueeze(1).repeat(1, ray_dirs.shape[1], 1).reshape(-1, 3)
+        else:
+            ray_dirs = input_dict['ray_dirs'].unsqueeze(0)
+            cam_loc = input_dict['ray_cam_loc']
+            ray_dirs_tmp = input_dict['ray_dirs_tmp'].unsqueeze(0)
+        return ray_dirs, cam_loc, ray_dirs_tmp
+
+    def forward(self, input_dict, indices, if_pixel_input=False):
+        ray_dirs, cam_loc, ray_dirs_tmp = self._rays(input_dict, if_pixel_input)
+        depth_scale = ray_dirs_tmp[0, :, 2:]
+        batch_size, num_pixels, _ = ray_dirs.shape
+        ray_dirs = ray_dirs.reshape(-1, 3).contiguous()
+        cam_loc = cam_loc.contiguous()
+        device = ray_dirs.device
+        noise = self._noise or {}
+        net = self.implicit_network
+        net.share(device)
+        self.rendering_network.share(device)
+        try:
+            z_vals, z_samples_eik = self.ray_sampler.get_z_vals(ray_dirs, cam_loc, self)
+            N, S = z_vals.shape
+            points_flat = (cam_loc.unsqueeze(1) + z_vals.unsqueeze(2) * ray_dirs.unsqueeze(1)).reshape(-1, 3)
+            P = N * S
+            x_all = points_flat
+            if self.training:
+                n_eik = batch_size * num_pixels
+                R = self.scene_bounding_sphere
+                eik_uniform = noise.get('eik_uniform')
+                if eik_uniform is None:
+                    eik_uniform = torch.empty(n_eik, 3, device=device).uniform_(-R, R)
+                eik_near = (cam_loc.unsqueeze(1) + z_samples_eik.unsqueeze(2) * ray_dirs.unsqueeze(1)).reshape(-1, 3)
+                eik = torch.cat([eik_uniform.to(device), eik_near], 0)
+                nei = noise.get('nei_rand')
+                if nei is None:
+                    nei = torch.rand_like(eik)
+                eik = torch.cat([eik, eik + (nei.to(device) - 0.5) * 0.01], 0)
+                x_all = torch.cat([points_flat, eik], 0)
+            # one fused evaluation for the ray samples (clamped, with features) and the eikonal points
+            sdf_all, feature_vectors, grad_all = net.evaluate(x_all, P, P, save=torch.is_grad_enabled())
+            sdf, gradients_sdf = sdf_all[:P], grad_all[:P]
+            rgb_flat = self.rendering_network(points_flat, gradients_sdf, ray_dirs, feature_vectors, indices,
+                                              if_pixel_input=if_pixel_input, samples_per_ray=S)['rgb']
+            rgb = rgb_flat.reshape(-1, S, 3)
+            weights, rgb_values, depth_values, normal_map = ops.CompositeFunction.apply(
+                z_vals, sdf, rgb_flat, gradients_sdf, self.density.get_beta(), depth_scale, self.white_bkgd,
+                [float(v) for v in self.bg_color.tolist()])
+        finally:
+            net.unshare()
+            self.rendering_network.unshare()
+
+        output = {
+            'rgb': rgb,
+            'rgb_values': rgb_values,
+            'depth_values': depth_values,
+            'z_vals': z_vals,
+            'depth_vals': z_vals * depth_scale,
+            'sdf': sdf.reshape(z_vals.shape),
+            'weights': weights,
+        }
+        if self.training:
+            grad_theta = grad_all[P:]
+            output['grad_theta'] = grad_theta[:grad_theta.shape[0] // 2]
+            output['grad_theta_nei'] = grad_theta[grad_theta.shape[0] // 2:]
+        # the compositor returns sum_i w_i n_i / (|n_i| + 1e-6) in world coordinates; rotate into the camera
+        if if_pixel_input:
+            rot = input_dict['ray_pose'][:, :3, :3].transpose(1, 2)
+            normal_map = (rot @ normal_map.unsqueeze(-1)).squeeze(-1)
+        else:
+            rot = input_dict['pose'][0, :3, :3].permute(1, 0).contiguous()
+            normal_map = (rot @ normal_map.permute(1, 0)).permute(1, 0).contiguous()
+        output['normal_map'] = normal_map
+        return output
+
+    def volume_rendering(self, z_vals, sdf):
+        """weights [N,S] (reference network.py:626-640); colours / normals are not needed for them."""
+        N, S = z_vals.shape
+        zeros = torch.zeros(N * S, 3, device=z_vals.device)
+        ones = torch.ones(N, device=z_vals.device)
+        return ops.CompositeFunction.apply(z_vals, sdf, zeros, zeros, self.density.get_beta(), ones, False,
+                                           [0.0, 0.0, 0.0])[0]

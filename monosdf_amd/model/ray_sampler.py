@@ -1,0 +1,112 @@
+"""Ray samplers (reference: code/model/ray_sampler.py).  ``ErrorBoundSampler.get_z_vals`` keeps the
+reference's signature ``(ray_dirs, cam_loc, model) -> (z_vals, z_samples_eik)``; the algorithm runs in
+csrc/sampler.hip (one wave per ray) with the SDF evaluations done by the fused forward kernel.
+One 4-byte device->host read per round carries the batch-global convergence test
+(``beta.max() > beta0``, reference ray_sampler.py:179)."""
+import ctypes as C
+import math
+
+import torch
+
+from .. import _lib, ops
+
+
+class RaySampler:
+    def __init__(self, near, far):
+        self.near, self.far = near, far
+
+
+class ErrorBoundSampler(RaySampler):
+    def __init__(self, scene_bounding_sphere, near, N_samples, N_samples_eval, N_samples_extra, eps, beta_iters,
+                 max_total_iters, inverse_sphere_bg=False, N_samples_inverse_sphere=0, add_tiny=1.0e-6):
+        super().__init__(near, 2.0 * scene_bounding_sphere * 1.75)
+        if inverse_sphere_bg:
+            raise NotImplementedError('monosdf_amd: inverse_sphere_bg is not used by any conf of the reference fork')
+        self.N_samples = N_samples
+        self.N_samples_eval = N_samples_eval
+        self.N_samples_extra = N_samples_extra
+        self.eps = eps
+        self.beta_iters = beta_iters
+        self.max_total_iters = max_total_iters
+        self.scene_bounding_sphere = scene_bounding_sphere
+        self.add_tiny = add_tiny
+        self.last_rounds = 0
+
+    def get_z_vals(self, ray_dirs, cam_loc, model):
+        dev = ray_dirs.device
+        if not ray_dirs.is_cuda:
+            raise RuntimeError('monosdf_amd: the sampler runs on the GPU only (no CPU fallback)')
+        ray_dirs = ray_dirs.detach().float().contiguous()
+        cam_loc = cam_loc.detach().float().contiguous()
+        N = ray_dirs.shape[0]
+        n_eval, n_final, n_extra = self.N_samples_eval, self.N_samples, self.N_samples_extra
+        m_max = n_eval * self.max_total_iters
+        S = n_final + n_extra + 2
+        noise = getattr(model, '_noise', None) or {}
+        training = bool(model.training)
+        net = model.implicit_network
+        beta0 = model.density.get_beta().detach().float().reshape(1).contiguous()
+        f32 = dict(device=dev, dtype=torch.float32)
+        z = torch.empty(N, m_max, **f32)
+        sdf = torch.empty(N, m_max, **f32)
+        new_z = torch.empty(N, n_eval, **f32)
+        new_pos = torch.empty(N, n_eval, device=dev, dtype=torch.int32)
+        pts = torch.empty(N * n_eval, 3, **f32)
+        beta = torch.empty(N, **f32)
+        flags = torch.zeros(2 * self.max_total_iters, device=dev, dtype=torch.int32)
+        final_z = torch.empty(N, n_final, **f32)
+        jitter = u_final = None
+        if training:
+            jitter = noise.get('jitter')
+            jitter = torch.rand(N, n_eval, **f32) if jitter is None else jitter.to(**f32).contiguous()
+            u_final = noise.get('final_u')
+            u_final = torch.rand(N, n_final, **f32) if u_final is None else u_final.to(**f32).contiguous()
+        lemma = float(1.0 / (4.0 * torch.log(torch.tensor(self.eps + 1.0))))
+        a = _lib.SamplerArgs()
+        a.ray_o, a.ray_d, a.N = cam_loc.data_ptr(), ray_dirs.data_ptr(), N
+        a.m_max, a.n_eval, a.n_final, a.n_extra = m_max, n_eval, n_final, n_extra
+        a.max_rounds, a.training, a.beta_iters = self.max_total_iters, int(training), self.beta_iters
+        a.near, a.far, a.bound = float(self.near), float(self.far), float(self.scene_bounding_sphere)
+        a.eps, a.add_tiny, a.lemma = float(self.eps), float(self.add_tiny), lemma
+        a.beta0, a.z, a.sdf = beta0.data_ptr(), z.data_ptr(), sdf.data_ptr()
+        a.new_z, a.new_pos, a.pts, a.beta = new_z.data_ptr(), new_pos.data_ptr(), pts.data_ptr(), beta.data_ptr()
+        a.jitter = jitter.data_ptr() if jitter is not None else None
+        a.u_final = u_final.data_ptr() if u_final is not None else None
+        a.final_z = final_z.data_ptr()
+        st = _lib.stream_ptr()
+        a.M = n_eval
+        _lib.call('msdf_sampler_init', C.byref(a), st)
+        rounds, M = 0, n_eval
+        with torch.no_grad():
+            while True:
+                new_sdf = net.get_sdf_vals(pts)                       # fused forward kernel, [N*n_eval, 1]
+                a.new_sdf = new_sdf.data_ptr()
+                a.M, a.round_idx = M, rounds
+                a.flag = flags.data_ptr() + 8 * rounds
+                _lib.call('msdf_sampler_beta', C.byref(a), st)
+                _lib.call('msdf_sampler_resample', C.byref(a), st)
+                more = int(flags[2 * rounds + 1].item())              # the one host sync of the round
+                rounds += 1
+                if not more:
+                    break
+                M += n_eval
+        self.last_rounds = rounds
+        # final set: 64 importance samples + near + far + 32 columns of the dense set
+        if n_extra > 0:
+            extra_idx = noise.get('extra_idx') if training else None
+            if extra_idx is None:
+                extra_idx = torch.randperm(M)[:n_extra] if training else torch.linspace(0, M - 1, n_extra).long()
+            extra_idx = extra_idx.to(device=dev, dtype=torch.int64).contiguous()
+        else:
+            extra_idx = torch.zeros(1, device=dev, dtype=torch.int64)
+        eik_idx = noise.get('eik_idx')
+        if eik_idx is None:
+            eik_idx = torch.randint(S, (N,))
+        eik_idx = eik_idx.to(device=dev, dtype=torch.int64).contiguous()
+        z_out = torch.empty(N, S, **f32)
+        z_eik = torch.empty(N, 1, **f32)
+        a.M = M
+        a.extra_idx, a.eik_idx = extra_idx.data_ptr(), eik_idx.data_ptr()
+        a.z_out, a.z_eik, a.pts_out = z_out.data_ptr(), z_eik.data_ptr(), None
+        _lib.call('msdf_sampler_finish', C.byref(a), st)
+        return z_out, z_eik

@@ -1,0 +1,404 @@
+"""torch.autograd bindings of the HIP kernels (device memory + streams come from PyTorch,
+all arithmetic on the hot path happens in libmonosdf_hip.so).
+
+Each Function owns one stage of the reference's autograd graph (reference:
+code/model/network.py) so DDP / Adam / checkpoints keep working on ordinary
+nn.Parameters: gradients of the *effective* (weight-normalised) matrices come out
+of the kernels and flow back to weight_g / weight_v through PyTorch's own autograd.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, plan as planlib
+
+
+def _need_cuda(t, name):
+    if not t.is_cuda:
+        raise RuntimeError('monosdf_amd: %s must be a GPU tensor (the HIP path has no CPU fallback)' % name)
+    if t.dtype != torch.float32:
+        raise RuntimeError('monosdf_amd: %s must be float32' % name)
+    return t.contiguous()
+
+
+def _pad64(n):
+    return (n + 63) // 64 * 64
+
+
+class FusedMlp:
+    """Device-side state of one fused network (plan, pack rules, maps, caches)."""
+
+    def __init__(self, mlp_plan, device):
+        self.mp = mlp_plan
+        self.device = device
+        self.rules_dev = torch.from_numpy(mlp_plan.rules_np).to(device)
+        self.maps_dev = torch.from_numpy(mlp_plan.maps_np).to(device)
+        self._wgrad_cache = {}
+        self.n_splits = 32
+
+    # -- weights -----------------------------------------------------------------
+    def pack(self, flat_w, flat_b):
+        mp = self.mp
+        flat_w = _need_cuda(flat_w.detach(), 'weights')
+        flat_b = _need_cuda(flat_b.detach(), 'biases')
+        assert flat_w.numel() == mp.n_w and flat_b.numel() == mp.n_b
+        wpack = torch.empty(mp.wpack_f4 * 4 + 2 * 17 * 64 * 4, device=self.device, dtype=torch.float32)
+        bpack = torch.empty(mp.bpack_f + 64, device=self.device, dtype=torch.float32)
+        _lib.call('msdf_pack_weights', C.byref(mp.plan), _lib.ptr(self.rules_dev), _lib.ptr(self.maps_dev),
+                  _lib.ptr(flat_w), _lib.ptr(flat_b), _lib.ptr(wpack), _lib.ptr(bpack), _lib.stream_ptr())
+        return wpack, bpack
+
+    # -- weight gradients ----------------------------------------------------------
+    def wgrad_program(self, P_pad):
+        key = P_pad
+        if key not in self._wgrad_cache:
+            n_splits = max(1, min(self.n_splits, P_pad // 32))
+            build = planlib.build_sdf_wgrad if self.mp.kind == 'sdf' else planlib.build_color_wgrad
+            prog = build(self.mp, P_pad, n_splits)
+            rules_dev = torch.from_numpy(prog.rules_bytes()).to(self.device)
+            self._wgrad_cache[key] = dict(prog=prog, rules=rules_dev, items={})
+        return self._wgrad_cache[key]
+
+    def run_wgrad(self, P_pad, base_addr):
+        """base_addr: buffer name -> tensor.  Returns the flat gradient [n_w + n_b]."""
+        ent = self.wgrad_program(P_pad)
+        prog = ent['prog']
+        addr = {k: t.data_ptr() for k, t in base_addr.items()}
+        key = tuple(sorted(addr.items()))
+        if key not in ent['items']:
+            if len(ent['items']) > 8:
+                ent['items'].clear()
+            ent['items'][key] = torch.from_numpy(prog.items_bytes(addr)).to(self.device)
+        items_dev = ent['items'][key]
+        part = torch.empty(prog.part_f + 64, device=self.device, dtype=torch.float32)
+        grad = torch.zeros(self.mp.n_w + self.mp.n_b, device=self.device, dtype=torch.float32)
+        st = _lib.stream_ptr()
+        _lib.call('msdf_wgrad', _lib.ptr(items_dev), len(prog.items), None, _lib.ptr(part), P_pad,
+                  prog.n_splits, st)
+        _lib.call('msdf_reduce', _lib.ptr(ent['rules']), len(prog.rules), _lib.ptr(self.maps_dev),
+                  _lib.ptr(part), _lib.ptr(grad), st)
+        return grad
+
+
+# ---------------------------------------------------------------------------
+# SDF network
+# ---------------------------------------------------------------------------
+def sdf_forward_nograd(mlp, wpack, bpack, x, aux, clamp_radius, sphere_scale):
+    """get_sdf_vals: forward only (sampler)."""
+    x = _need_cuda(x, 'points')
+    P = x.shape[0]
+    out = torch.empty(P, 1, device=x.device, dtype=torch.float32)
+    _lib.call('msdf_sdf_forward', C.byref(mlp.mp.plan), _lib.ptr(wpack), _lib.ptr(bpack), _lib.ptr(x),
+              _lib.ptr(aux), P, float(clamp_radius), float(sphere_scale), _lib.ptr(out), _lib.stream_ptr())
+    return out
+
+
+class SdfMlpFunction(torch.autograd.Function):
+    """(x, aux, W, b) -> (sdf [P,1], feat [n_feat,F], d sdf/dx [P,3], d sdf/d aux [P,A])."""
+
+    @staticmethod
+    def forward(ctx, x, aux, flat_w, flat_b, wpack, bpack, mlp, n_clamp, n_feat, clamp_radius,
+                sphere_scale, save):
+        mp = mlp.mp
+        plan = mp.plan
+        x = _need_cuda(x.detach(), 'points')
+        P = x.shape[0]
+        P_pad = _pad64(max(P, 1))
+        dev = x.device
+        has_aux = plan.aux_tiles > 0
+        if has_aux:
+            aux = _need_cuda(aux.detach(), 'aux features')
+        woff, total = planlib.sdf_workspace(mp, P_pad)
+        if not save:
+            total = woff['PM']           # only H is touched in inference
+        ws = torch.empty(max(total, 64), device=dev, dtype=torch.float32)
+        F = 16 * plan.feat_tiles
+        sdf = torch.empty(P, 1, device=dev, dtype=torch.float32)
+        feat = torch.empty(n_feat, F, device=dev, dtype=torch.float32)
+        nrm = torch.empty(P, 3, device=dev, dtype=torch.float32)
+        r_aux = torch.empty(P, 16 * plan.aux_tiles, device=dev, dtype=torch.float32) if has_aux else None
+        clamped = torch.empty(max(P, 1), device=dev, dtype=torch.uint8)
+        a = _lib.FgArgs()
+        a.wpack, a.bpack, a.x, a.aux = wpack.data_ptr(), bpack.data_ptr(), x.data_ptr(), \
+            (aux.data_ptr() if has_aux else None)
+        a.P, a.P_pad, a.n_clamp, a.n_feat = P, P_pad, n_clamp, n_feat
+        a.clamp_radius, a.sphere_scale = float(clamp_radius), float(sphere_scale)
+        a.sdf, a.feat, a.nrm = sdf.data_ptr(), feat.data_ptr(), nrm.data_ptr()
+        a.r_aux = r_aux.data_ptr() if has_aux else None
+        a.clamped = clamped.data_ptr()
+        base = ws.data_ptr()
+        a.H = base + 4 * woff['H']
+        a.PM = base + 4 * woff['PM'] if save else None
+        a.IN0 = base + 4 * woff['IN0'] if save else None
+        a.save = 1 if save else 0
+        if P > 0:
+            _lib.call('msdf_sdf_fwd_grad', C.byref(plan), C.byref(a), _lib.stream_ptr())
+        ctx.mlp, ctx.P, ctx.P_pad, ctx.n_feat, ctx.saved = mlp, P, P_pad, n_feat, save
+        ctx.has_aux = has_aux
+        ctx.save_for_backward(x, ws, clamped, wpack, bpack)
+        if has_aux:
+            return sdf, feat, nrm, r_aux
+        return sdf, feat, nrm, None
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_sdf, g_feat, g_nrm, g_raux):
+        if not ctx.saved:
+            raise RuntimeError('monosdf_amd: backward through an inference-mode SDF evaluation')
+        x, ws, clamped, wpack, bpack = ctx.saved_tensors
+        mlp, P, P_pad = ctx.mlp, ctx.P, ctx.P_pad
+        mp = mlp.mp
+        plan = mp.plan
+        dev = x.device
+        woff, _ = planlib.sdf_workspace(mp, P_pad)
+        cont = lambda t: None if t is None else t.contiguous()
+        g_sdf, g_feat, g_nrm, g_raux = cont(g_sdf), cont(g_feat), cont(g_nrm), cont(g_raux)
+        g_aux = torch.empty(P, 16 * plan.aux_tiles, device=dev, dtype=torch.float32) if ctx.has_aux else None
+        b = _lib.BwArgs()
+        b.wpack, b.bpack, b.x = wpack.data_ptr(), bpack.data_ptr(), x.data_ptr()
+        b.P, b.P_pad, b.n_feat = P, P_pad, ctx.n_feat
+        b.g_sdf = g_sdf.data_ptr() if g_sdf is not None else None
+        b.g_feat = g_feat.data_ptr() if (g_feat is not None and ctx.n_feat > 0) else None
+        b.g_nrm = g_nrm.data_ptr() if g_nrm is not None else None
+        b.g_raux = g_raux.data_ptr() if (g_raux is not None and ctx.has_aux) else None
+        b.clamped = clamped.data_ptr()
+        base = ws.data_ptr()
+        for k in ('H', 'PM', 'QB', 'T', 'AB', 'GSDF', 'QLAST'):
+            setattr(b, k, base + 4 * woff[k])
+        b.g_aux = g_aux.data_ptr() if g_aux is not None else None
+        if P > 0:
+            _lib.call('msdf_sdf_backward', C.byref(plan), C.byref(b), _lib.stream_ptr())
+            grad = mlp.run_wgrad(P_pad, {'ws': ws})
+        else:
+            grad = torch.zeros(mp.n_w + mp.n_b, device=dev)
+        return (None, g_aux, grad[:mp.n_w], grad[mp.n_w:], None, None, None, None, None, None, None, None)
+
+
+# ---------------------------------------------------------------------------
+# colour network
+# ---------------------------------------------------------------------------
+class ColorMlpFunction(torch.autograd.Function):
+    """(points, per-ray dirs, normals, feat, per-ray code, W, b) -> rgb [P,3]."""
+
+    @staticmethod
+    def forward(ctx, x, dirs, nrm, feat, code, flat_w, flat_b, wpack, bpack, cmlp, spr, save):
+        mp = cmlp.mp
+        plan = mp.plan
+        x = _need_cuda(x.detach(), 'points')
+        dirs = _need_cuda(dirs.detach(), 'view dirs')
+        nrm = _need_cuda(nrm.detach(), 'normals')
+        feat = _need_cuda(feat.detach(), 'features')
+        P = x.shape[0]
+        P_pad = _pad64(max(P, 1))
+        dev = x.device
+        if feat.shape[1] != 16 * plan.layer[0].kt:
+            raise RuntimeError('monosdf_amd: feature width must be a multiple of 16')
+        has_code = plan.aux_tiles > 0
+        if has_code:
+            code = _need_cuda(code.detach(), 'image code')
+        woff, total = planlib.color_workspace(mp, P_pad)
+        ws = torch.empty(max(total if save else 64, 64), device=dev, dtype=torch.float32)
+        rgb = torch.empty(P, 3, device=dev, dtype=torch.float32)
+        a = _lib.ColorFwdArgs()
+        a.wpack, a.bpack = wpack.data_ptr(), bpack.data_ptr()
+        a.x, a.dirs, a.nrm, a.feat = x.data_ptr(), dirs.data_ptr(), nrm.data_ptr(), feat.data_ptr()
+        a.code = code.data_ptr() if has_code else None
+        a.P, a.P_pad, a.spr, a.save = P, P_pad, int(spr), 1 if save else 0
+        a.rgb = rgb.data_ptr()
+        base = ws.data_ptr()
+        a.H = base + 4 * woff['H'] if save else None
+        a.MISC = base + 4 * woff['MISC'] if save else None
+        if P > 0:
+            _lib.call('msdf_color_forward', C.byref(plan), C.byref(a), _lib.stream_ptr())
+        ctx.cmlp, ctx.P, ctx.P_pad, ctx.saved, ctx.has_code, ctx.spr = cmlp, P, P_pad, save, has_code, spr
+        ctx.save_for_backward(rgb, feat, ws, wpack, bpack)
+        return rgb
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_rgb):
+        if not ctx.saved:
+            raise RuntimeError('monosdf_amd: backward through an inference-mode colour evaluation')
+        rgb, feat, ws, wpack, bpack = ctx.saved_tensors
+        cmlp, P, P_pad = ctx.cmlp, ctx.P, ctx.P_pad
+        mp = cmlp.mp
+        plan = mp.plan
+        dev = rgb.device
+        woff, _ = planlib.color_workspace(mp, P_pad)
+        g_rgb = g_rgb.contiguous()
+        g_feat = torch.empty_like(feat)
+        g_misc = torch.empty(P, 16 * mp.misc_tiles, device=dev, dtype=torch.float32)
+        b = _lib.ColorBwdArgs()
+        b.wpack, b.bpack, b.rgb, b.g_rgb = wpack.data_ptr(), bpack.data_ptr(), rgb.data_ptr(), g_rgb.data_ptr()
+        b.P, b.P_pad = P, P_pad
+        base = ws.data_ptr()
+        b.H, b.AB = base + 4 * woff['H'], base + 4 * woff['AB']
+        b.g_feat, b.g_misc = g_feat.data_ptr(), g_misc.data_ptr()
+        if P > 0:
+            _lib.call('msdf_color_backward', C.byref(plan), C.byref(b), _lib.stream_ptr())
+            grad = cmlp.run_wgrad(P_pad, {'ws': ws, 'feat': feat})
+        else:
+            grad = torch.zeros(mp.n_w + mp.n_b, device=dev)
+        g_nrm = g_misc[:, mp.lead - 3:mp.lead].contiguous() if plan.mode == 1 else None
+        g_code = None
+        if ctx.has_code:
+            g_code = g_misc[:, 48:].reshape(P // ctx.spr, ctx.spr, -1).sum(1)
+        return (None, None, g_nrm, g_feat, g_code, grad[:mp.n_w], grad[mp.n_w:], None, None, None, None, None)
+
+
+# ---------------------------------------------------------------------------
+# compositor
+# ---------------------------------------------------------------------------
+class CompositeFunction(torch.autograd.Function):
+    """(z, sdf, rgb, normals, beta, depth_scale) -> weights, rgb_values, depth_values, normal_map."""
+
+    @staticmethod
+    def forward(ctx, z, sdf, rgb, nrm, beta, depth_scale, white_bkgd, bg):
+        z = _need_cuda(z.detach(), 'z_vals')
+        N, S = z.shape
+        ctx.in_shapes = (sdf.shape, rgb.shape, nrm.shape)
+        sdf = _need_cuda(sdf.detach(), 'sdf').reshape(N, S)
+        rgb = _need_cuda(rgb.detach(), 'rgb').reshape(N, S, 3)
+        nrm = _need_cuda(nrm.detach(), 'normals').reshape(N, S, 3)
+        beta = _need_cuda(beta.detach(), 'beta').reshape(1)
+        depth_scale = _need_cuda(depth_scale.detach(), 'depth_scale').reshape(N)
+        dev = z.device
+        weights = torch.empty(N, S, device=dev)
+        rgb_values = torch.empty(N, 3, device=dev)
+        depth_values = torch.empty(N, 1, device=dev)
+        normal_map = torch.empty(N, 3, device=dev)
+        wsum = torch.empty(max(N, 1), device=dev)
+        a = _lib.CompositeArgs()
+        a.z, a.sdf, a.rgb, a.nrm = z.data_ptr(), sdf.data_ptr(), rgb.data_ptr(), nrm.data_ptr()
+        a.beta, a.depth_scale = beta.data_ptr(), depth_scale.data_ptr()
+        a.N, a.S, a.white_bkgd = N, S, 1 if white_bkgd else 0
+        a.bg0, a.bg1, a.bg2 = [float(v) for v in bg]
+        a.weights, a.rgb_values, a.depth_values = weights.data_ptr(), rgb_values.data_ptr(), depth_values.data_ptr()
+        a.normal_map, a.wsum = normal_map.data_ptr(), wsum.data_ptr()
+        _lib.call('msdf_composite_forward', C.byref(a), _lib.stream_ptr())
+        ctx.save_for_backward(z, sdf, rgb, nrm, beta, depth_scale, weights, wsum, depth_values)
+        ctx.white_bkgd, ctx.bg = white_bkgd, [float(v) for v in bg]
+        return weights, rgb_values, depth_values, normal_map
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_w, g_rgbv, g_depth, g_nmap):
+        z, sdf, rgb, nrm, beta, depth_scale, weights, wsum, depth_values = ctx.saved_tensors
+        N, S = z.shape
+        dev = z.device
+        cont = lambda t: None if t is None else t.contiguous()
+        g_w, g_rgbv, g_depth, g_nmap = cont(g_w), cont(g_rgbv), cont(g_depth), cont(g_nmap)
+        g_sdf = torch.empty(N, S, device=dev)
+        g_rgb = torch.empty(N, S, 3, device=dev)
+        g_nrm = torch.empty(N, S, 3, device=dev)
+        g_beta_part = torch.empty(max(N, 1), device=dev)
+        b = _lib.CompositeBwdArgs()
+        b.z, b.sdf, b.rgb, b.nrm = z.data_ptr(), sdf.data_ptr(), rgb.data_ptr(), nrm.data_ptr()
+        b.beta, b.depth_scale = beta.data_ptr(), depth_scale.data_ptr()
+        b.weights, b.wsum, b.depth_values = weights.data_ptr(), wsum.data_ptr(), depth_values.data_ptr()
+        b.g_rgb_values = g_rgbv.data_ptr() if g_rgbv is not None else None
+        b.g_depth = g_depth.data_ptr() if g_depth is not None else None
+        b.g_normal = g_nmap.data_ptr() if g_nmap is not None else None
+        b.g_weights = g_w.data_ptr() if g_w is not None else None
+        b.N, b.S, b.white_bkgd = N, S, 1 if ctx.white_bkgd else 0
+        b.bg0, b.bg1, b.bg2 = ctx.bg
+        b.g_sdf, b.g_rgb, b.g_nrm, b.g_beta_part = g_sdf.data_ptr(), g_rgb.data_ptr(), g_nrm.data_ptr(), \
+            g_beta_part.data_ptr()
+        _lib.call('msdf_composite_backward', C.byref(b), _lib.stream_ptr())
+        g_beta = g_beta_part[:N].sum().reshape(beta.shape)
+        sh = ctx.in_shapes
+        return (None, g_sdf.reshape(sh[0]), g_rgb.reshape(sh[1]), g_nrm.reshape(sh[2]), g_beta, None, None, None)
+
+
+# ---------------------------------------------------------------------------
+# hash grid (mirrors the reference's two autograd Functions, hashencoder/hashgrid.py:14-101)
+# ---------------------------------------------------------------------------
+class HashEncodeFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inputs, embeddings, offsets, S, H, calc_grad_inputs):
+        inputs = _need_cuda(inputs, 'inputs')
+        embeddings = _need_cuda(embeddings, 'embeddings')
+        offsets = offsets.contiguous()
+        if offsets.dtype != torch.int32 or not offsets.is_cuda:
+            raise RuntimeError('monosdf_amd: offsets must be a GPU int32 tensor')
+        B, D = inputs.shape
+        L, Cdim = offsets.shape[0] - 1, embeddings.shape[1]
+        outputs = torch.empty(L, B, Cdim, device=inputs.device, dtype=torch.float32)
+        dy_dx = torch.empty(B, L * D * Cdim if calc_grad_inputs else 1, device=inputs.device, dtype=torch.float32)
+        _lib.call('msdf_hash_encode_forward', _lib.ptr(inputs), _lib.ptr(embeddings), _lib.ptr(offsets),
+                  _lib.ptr(outputs), B, D, Cdim, L, float(S), int(H), int(bool(calc_grad_inputs)),
+                  _lib.ptr(dy_dx), _lib.stream_ptr())
+        ctx.save_for_backward(inputs, embeddings, offsets, dy_dx)
+        ctx.dims = (B, D, Cdim, L, float(S), int(H))
+        ctx.calc_grad_inputs = bool(calc_grad_inputs)
+        return outputs.permute(1, 0, 2).reshape(B, L * Cdim)
+
+    @staticmethod
+    def backward(ctx, grad):
+        inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
+        B, D, Cdim, L, S, H = ctx.dims
+        grad = grad.view(B, L, Cdim).permute(1, 0, 2).contiguous()
+        g_in, g_emb = HashEncodeBackwardFunction.apply(grad, inputs, embeddings, offsets, dy_dx, ctx.dims,
+                                                       ctx.calc_grad_inputs, True)
+        return (g_in if ctx.calc_grad_inputs else None), g_emb, None, None, None, None
+
+
+class HashEncodeBackwardFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, grad, inputs, embeddings, offsets, dy_dx, dims, calc_grad_inputs, want_emb=True):
+        B, D, Cdim, L, S, H = dims
+        grad = _need_cuda(grad, 'grad')
+        g_in = torch.zeros_like(inputs)
+        # the reference always scatters into grad_embeddings, even when autograd discards it
+        # (SURVEY 8a11); want_emb=False skips that wasted pass, the result the caller sees is identical
+        g_emb = torch.zeros_like(embeddings) if want_emb else None
+        _lib.call('msdf_hash_encode_backward', _lib.ptr(grad), _lib.ptr(inputs), _lib.ptr(embeddings),
+                  _lib.ptr(offsets), _lib.ptr(g_emb), B, D, Cdim, L, S, H, int(calc_grad_inputs),
+                  _lib.ptr(dy_dx), _lib.ptr(g_in), _lib.stream_ptr())
+        if g_emb is None:
+            g_emb = embeddings.new_zeros(1)
+        ctx.save_for_backward(grad, inputs, embeddings, offsets, dy_dx)
+        ctx.dims, ctx.calc_grad_inputs = dims, calc_grad_inputs
+        return g_in, g_emb
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gg_in, gg_emb):
+        # like the reference: gg_emb is ignored and nothing flows to the inputs (hashgrid.py:87,101)
+        grad, inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
+        B, D, Cdim, L, S, H = ctx.dims
+        gg_in = _need_cuda(gg_in, 'grad_grad_inputs')
+        grad_grad = torch.zeros_like(grad)
+        grad2_emb = torch.zeros_like(embeddings)
+        _lib.call('msdf_hash_encode_second_backward', _lib.ptr(grad), _lib.ptr(inputs), _lib.ptr(embeddings),
+                  _lib.ptr(offsets), B, D, Cdim, L, S, H, int(ctx.calc_grad_inputs), _lib.ptr(dy_dx),
+                  _lib.ptr(gg_in), _lib.ptr(grad_grad), _lib.ptr(grad2_emb), _lib.stream_ptr())
+        return grad_grad, None, grad2_emb, None, None, None, None, None
+
+
+class HashEncodeWithJacobian(torch.autograd.Function):
+    """Forward that also returns dy_dx (for the fused-MLP path, where d/dx is applied explicitly)."""
+
+    @staticmethod
+    def forward(ctx, inputs, embeddings, offsets, S, H):
+        inputs = _need_cuda(inputs, 'inputs')
+        embeddings_c = _need_cuda(embeddings, 'embeddings')
+        B, D = inputs.shape
+        L, Cdim = offsets.shape[0] - 1, embeddings.shape[1]
+        outputs = torch.empty(L, B, Cdim, device=inputs.device, dtype=torch.float32)
+        dy_dx = torch.empty(B, L * D * Cdim, device=inputs.device, dtype=torch.float32)
+        _lib.call('msdf_hash_encode_forward', _lib.ptr(inputs), _lib.ptr(embeddings_c), _lib.ptr(offsets),
+                  _lib.ptr(outputs), B, D, Cdim, L, float(S), int(H), 1, _lib.ptr(dy_dx), _lib.stream_ptr())
+        ctx.save_for_backward(inputs, embeddings_c, offsets, dy_dx)
+        ctx.dims = (B, D, Cdim, L, float(S), int(H))
+        ctx.mark_non_differentiable(dy_dx)
+        return outputs.permute(1, 0, 2).reshape(B, L * Cdim), dy_dx
+
+    @staticmethod
+    def backward(ctx, grad, _g_dy):
+        inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
+        B, D, Cdim, L, S, H = ctx.dims
+        grad = grad.view(B, L, Cdim).permute(1, 0, 2).contiguous()
+        _, g_emb = HashEncodeBackwardFunction.apply(grad, inputs, embeddings, offsets, dy_dx, ctx.dims, False, True)
+        return None, g_emb, None, None, None

@@ -1,0 +1,390 @@
+"""Host-side geometry of the fused MLP kernels: slot layouts, weight-pack rules,
+workspace layout, weight-gradient work items and reduction rules.
+
+A "slot" is one lane-register position of the kernels' activation tiles (16 slots
+per tile, see csrc/mlp_core.h).  The maps built here say which original row /
+column of a reference weight matrix (reference: code/model/network.py:43-75 for
+the SDF network's dims/skip logic, 344-384 for the colour network) each slot
+carries; padding slots map to -1 and get zero weights.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+
+MT = _lib.MAX_TILES
+
+
+def _ceil16(n):
+    return (n + 15) // 16
+
+
+def _even(n):
+    return (n + 1) & ~1
+
+
+def _pad_k(k):
+    """K of a packed operand: 12..16 tiles share the unrolled K=16 kernel path."""
+    return 16 if 12 <= k <= 16 else k
+
+
+def _ident_map(n_valid, n_tiles, shift=0):
+    m = np.full(16 * n_tiles, -1, dtype=np.int32)
+    m[:n_valid] = np.arange(n_valid, dtype=np.int32) + shift
+    return m
+
+
+class MlpPlan:
+    """Everything static about one network: ctypes plan, pack rules, maps, sizes."""
+
+    def __init__(self):
+        self.plan = _lib.Plan()
+        self.rules = []          # PackRule per pack unit
+        self.maps = []           # list of int32 arrays, concatenated at finalise
+        self._map_off = 0
+        self.w_shapes = []       # original (rows, cols) per weight tensor
+        self.unit_weight = []    # pack unit -> index of the weight tensor
+        self.wpack_f4 = 0
+        self.bpack_f = 0
+        self.rowmaps = []        # per unit: (offset, array)
+        self.colmaps = []
+
+    def add_map(self, arr):
+        off = self._map_off
+        self.maps.append(np.ascontiguousarray(arr, dtype=np.int32))
+        self._map_off += len(arr)
+        return off
+
+    def add_unit(self, widx, rowmap, colmap, scale, skip_tile=-1):
+        u = len(self.rules)
+        ot, kt = len(rowmap) // 16, len(colmap) // 16
+        if ot > MT or kt > MT:
+            raise RuntimeError('monosdf_amd: layer with %d/%d tiles exceeds the %d-tile register file layout'
+                               % (kt, ot, MT))
+        L = self.plan.layer[u]
+        L.kt, L.ot, L.ktp, L.otp = kt, ot, _pad_k(kt), _pad_k(ot)
+        L.wf_off = self.wpack_f4
+        self.wpack_f4 += _even(ot) * L.ktp * 64
+        L.wb_off = self.wpack_f4
+        self.wpack_f4 += _even(kt) * L.otp * 64
+        L.bias_off = self.bpack_f
+        self.bpack_f += 16 * ot
+        L.skip_tile = skip_tile
+        r = _lib.PackRule()
+        rows, cols = self.w_shapes[widx]
+        r.rows, r.cols = rows, cols
+        r.rowmap_off = self.add_map(rowmap)
+        r.colmap_off = self.add_map(colmap)
+        r.scale = scale
+        self.rules.append(r)
+        self.unit_weight.append(widx)
+        self.rowmaps.append((r.rowmap_off, rowmap))
+        self.colmaps.append((r.colmap_off, colmap))
+        return u
+
+    def finalise(self):
+        # flat weight / bias buffers are the concatenation of the original tensors
+        w_off = np.cumsum([0] + [r * c for r, c in self.w_shapes])
+        b_off = np.cumsum([0] + [r for r, _ in self.w_shapes])
+        self.w_offsets, self.b_offsets = w_off, b_off
+        for u, r in enumerate(self.rules):
+            r.w_off = int(w_off[self.unit_weight[u]])
+            r.b_off = int(b_off[self.unit_weight[u]])
+        self.n_w = int(w_off[-1])
+        self.n_b = int(b_off[-1])
+        self.plan.n_layers = len(self.rules)
+        self.maps_np = np.concatenate(self.maps) if self.maps else np.zeros(1, np.int32)
+        self.rules_np = np.frombuffer(b''.join(bytes(r) for r in self.rules), dtype=np.uint8).copy()
+
+
+def build_sdf_plan(w_shapes, skip_in, n_freqs, aux_cols, aux_active, feature_size, d_in=3):
+    """Plan of ImplicitNetwork / ImplicitNetworkGrid.
+
+    w_shapes: [(out_l, in_l)] of the reference's nn.Linear layers; aux_cols: width of the
+    hash-feature block in the network input (0 for ImplicitNetwork, 32 for the grid class);
+    aux_active: whether those features are non-zero (use_grid_feature)."""
+    mp = MlpPlan()
+    mp.w_shapes = list(w_shapes)
+    n = len(w_shapes)
+    pe_dim = d_in + 2 * d_in * n_freqs if n_freqs > 0 else d_in
+    d0 = pe_dim + aux_cols
+    assert w_shapes[0][1] == d0, (w_shapes[0], d0)
+    e_tiles = 3
+    if pe_dim > 48:
+        raise RuntimeError('monosdf_amd: positional encoding wider than 48 is not supported')
+    aux_tiles = _ceil16(aux_cols) if aux_active else 0
+    if aux_tiles > 2:
+        raise RuntimeError('monosdf_amd: more than 32 grid features are not supported')
+    in0_tiles = e_tiles + aux_tiles
+    in0_map = np.full(16 * in0_tiles, -1, dtype=np.int32)
+    in0_map[:pe_dim] = np.arange(pe_dim)
+    if aux_tiles:
+        in0_map[48:48 + aux_cols] = pe_dim + np.arange(aux_cols)
+    P = mp.plan
+    P.e_tiles, P.aux_tiles, P.n_freqs = e_tiles, aux_tiles, n_freqs
+    feat_tiles = _ceil16(feature_size)
+    P.feat_tiles = feat_tiles
+    P.sdf_slot = 16 * feat_tiles
+    hpre = qpre = abpre = 0
+    prev_ot, prev_out = None, None
+    for l, (out, inn) in enumerate(w_shapes):
+        last = (l == n - 1)
+        if last:
+            assert out == 1 + feature_size
+            rowmap = np.full(16 * (feat_tiles + 1), -1, dtype=np.int32)
+            rowmap[:feature_size] = 1 + np.arange(feature_size)
+            rowmap[16 * feat_tiles] = 0
+        else:
+            rowmap = _ident_map(out, _ceil16(out))
+        skip_tile = -1
+        scale = 1.0
+        if l == 0:
+            colmap = in0_map.copy()
+        elif l in skip_in:
+            assert inn == prev_out + d0
+            skip_tile = prev_ot
+            colmap = np.concatenate([_ident_map(prev_out, prev_ot),
+                                     np.where(in0_map >= 0, in0_map + prev_out, -1).astype(np.int32)])
+            scale = 1.0 / math.sqrt(2.0)
+        else:
+            assert inn == prev_out, (l, inn, prev_out)
+            colmap = _ident_map(prev_out, prev_ot)
+        u = mp.add_unit(l, rowmap, colmap, scale, skip_tile)
+        L = P.layer[u]
+        L.hpre, L.qpre, L.abpre = hpre, qpre, abpre
+        if not last:
+            hpre += 16 * L.ot
+            qpre += 16 * L.kt
+        abpre += 16 * L.ot
+        prev_ot, prev_out = L.ot, out
+    P.hsum, P.qsum, P.absum = hpre, qpre, abpre
+    P.wsdf_off = mp.bpack_f
+    mp.bpack_f += 16 * P.layer[n - 1].kt
+    P.mode, P.out_act = 0, 0
+    mp.in0_tiles = in0_tiles
+    mp.kind = 'sdf'
+    mp.finalise()
+    return mp
+
+
+def build_color_plan(w_shapes, mode, n_freqs_view, feature_size, code_cols=0, out_relu=False):
+    """Plan of RenderingNetwork (mode 'idr' or 'nerf'); pack units 0/1 split the first layer."""
+    mp = MlpPlan()
+    mp.w_shapes = list(w_shapes)
+    n = len(w_shapes)
+    pev = 3 + 6 * n_freqs_view if n_freqs_view > 0 else 3
+    lead = (3 + pev + 3) if mode == 'idr' else pev            # columns before the feature block
+    if lead > 48:
+        raise RuntimeError('monosdf_amd: view encoding too wide')
+    assert w_shapes[0][1] == lead + feature_size + code_cols, (w_shapes[0], lead, feature_size, code_cols)
+    feat_tiles = _ceil16(feature_size)
+    aux_tiles = _ceil16(code_cols)
+    if aux_tiles > 2:
+        raise RuntimeError('monosdf_amd: per-image code wider than 32 is not supported')
+    P = mp.plan
+    P.e_tiles, P.aux_tiles, P.n_freqs, P.feat_tiles = 3, aux_tiles, n_freqs_view, feat_tiles
+    P.mode = 1 if mode == 'idr' else 0
+    P.out_act = 1 if out_relu else 0
+    P.wsdf_off = -1
+    P.sdf_slot = 0
+    out0 = w_shapes[0][0]
+    row0 = _ident_map(out0, _ceil16(out0))
+    feat_map = _ident_map(feature_size, feat_tiles, shift=lead)
+    misc_map = np.full(16 * (3 + aux_tiles), -1, dtype=np.int32)
+    misc_map[:lead] = np.arange(lead)
+    if aux_tiles:
+        misc_map[48:48 + code_cols] = lead + feature_size + np.arange(code_cols)
+    u0 = mp.add_unit(0, row0, feat_map, 1.0)
+    u1 = mp.add_unit(0, row0, misc_map, 1.0)
+    P.layer[u0].abpre = P.layer[u1].abpre = 0
+    P.layer[u0].hpre = P.layer[u1].hpre = 0
+    abpre, hpre = 16 * P.layer[u0].ot, 0
+    prev_out, prev_ot = out0, P.layer[u0].ot
+    for l in range(1, n):
+        out, inn = w_shapes[l]
+        assert inn == prev_out
+        rowmap = _ident_map(out, _ceil16(out))
+        u = mp.add_unit(l, rowmap, _ident_map(prev_out, prev_ot), 1.0)
+        L = P.layer[u]
+        L.abpre, L.hpre = abpre, hpre
+        abpre += 16 * L.ot
+        hpre += 16 * L.kt
+        prev_out, prev_ot = out, L.ot
+    P.hsum, P.absum, P.qsum = hpre, abpre, 0
+    mp.misc_tiles = 3 + aux_tiles
+    mp.lead = lead
+    mp.kind = 'color'
+    mp.finalise()
+    return mp
+
+
+# ---------------------------------------------------------------------------
+# workspace layouts (float offsets for a given P_pad)
+# ---------------------------------------------------------------------------
+def sdf_workspace(mp, P_pad):
+    P = mp.plan
+    n = P.n_layers
+    sizes = [('H', P.hsum * P_pad), ('PM', P.hsum * P_pad), ('IN0', 16 * mp.in0_tiles * P_pad),
+             ('QB', P.qsum * P_pad), ('T', P.hsum * P_pad), ('AB', P.absum * P_pad),
+             ('GSDF', P_pad), ('QLAST', 16 * P.layer[n - 1].kt * P_pad)]
+    off, total = {}, 0
+    for k, s in sizes:
+        off[k] = total
+        total += (s + 63) & ~63
+    return off, total
+
+
+def color_workspace(mp, P_pad):
+    P = mp.plan
+    sizes = [('H', P.hsum * P_pad), ('MISC', 16 * mp.misc_tiles * P_pad), ('AB', P.absum * P_pad)]
+    off, total = {}, 0
+    for k, s in sizes:
+        off[k] = total
+        total += (s + 63) & ~63
+    return off, total
+
+
+# ---------------------------------------------------------------------------
+# weight-gradient work items + reduction rules
+# ---------------------------------------------------------------------------
+class WgradProgram:
+    """Work items (with absolute device addresses filled in per call) and reduce rules."""
+
+    def __init__(self, n_splits):
+        self.n_splits = n_splits
+        self.items = []      # dicts: x, y, v = (buffer name, float offset) ; part/colsum/vrow offsets
+        self.rules = []      # ReduceRule
+        self.part_f = 0
+
+    def alloc(self, n):
+        off = self.part_f
+        self.part_f += n
+        return off
+
+    def add_item(self, x, x_ld, wx, y, y_ld, wy, part_off, colsum_off=-1, v=None, vrow_off=-1):
+        assert wx % 16 == 0 and wy % 16 == 0 and wx <= 256 and wy <= 256, (wx, wy)
+        self.items.append(dict(x=x, y=y, v=v, x_ld=x_ld, y_ld=y_ld, wx=wx, wy=wy, part_off=part_off,
+                               colsum_off=colsum_off, vrow_off=vrow_off))
+
+    def add_rule(self, part_off, n_blocks, wx, wy, rowmap_off, colmap_off, dst_off, dst_ld, scale,
+                 fixed_row=0):
+        r = _lib.ReduceRule()
+        r.part_off, r.dst_off, r.n_blocks, r.wx, r.wy = part_off, dst_off, n_blocks, wx, wy
+        r.rowmap_off, r.colmap_off, r.dst_ld, r.fixed_row, r.scale = rowmap_off, colmap_off, dst_ld, fixed_row, scale
+        self.rules.append(r)
+
+    def rules_bytes(self):
+        return np.frombuffer(b''.join(bytes(r) for r in self.rules), dtype=np.uint8).copy()
+
+    def items_bytes(self, base_addr):
+        """base_addr: dict buffer name -> absolute device address (bytes)."""
+        out = []
+        for it in self.items:
+            w = _lib.WgradItem()
+            ax = base_addr[it['x'][0]]
+            w.x_off = ax // 4 + it['x'][1]
+            ay = base_addr[it['y'][0]] if it['y'] is not None else ax
+            w.y_off = ay // 4 + (it['y'][1] if it['y'] is not None else 0)
+            w.v_off = (base_addr[it['v'][0]] // 4 + it['v'][1]) if it['v'] is not None else -1
+            w.part_off, w.colsum_off, w.vrow_off = it['part_off'], it['colsum_off'], it['vrow_off']
+            w.x_ld, w.y_ld, w.wx, w.wy = it['x_ld'], it['y_ld'], it['wx'], it['wy']
+            out.append(bytes(w))
+        return np.frombuffer(b''.join(out), dtype=np.uint8).copy()
+
+
+def _col_parts(L, in0_tiles):
+    """Column ranges (slot start, width) of a layer's input, each <= 256 wide."""
+    if L.skip_tile >= 0:
+        return [(0, 16 * L.skip_tile), (16 * L.skip_tile, 16 * in0_tiles)]
+    return [(0, 16 * L.kt)]
+
+
+def build_sdf_wgrad(mp, P_pad, n_splits):
+    """Items/rules of d W_l, d b_l for the SDF network.  Buffer names refer to the workspace
+    ('ws', float offsets from sdf_workspace)."""
+    P = mp.plan
+    n = P.n_layers
+    S = n_splits
+    woff, _ = sdf_workspace(mp, P_pad)
+    prog = WgradProgram(S)
+    dW_off, dB_off = mp.w_offsets, mp.b_offsets + mp.n_w     # gradient buffer: all dW then all db
+    for l in range(n):
+        L = P.layer[l]
+        rows, cols = mp.w_shapes[l]
+        rm_off = mp.rowmaps[l][0]
+        cm_off = mp.colmaps[l][0]
+        scale = float(mp.rules[l].scale)
+        last = (l == n - 1)
+        wx = 16 * (P.feat_tiles if last else L.ot)
+        x_ld = 16 * L.ot
+        ab = ('ws', woff['AB'] + L.abpre * P_pad)
+        colsum_off = prog.alloc(S * wx)
+        for pi, (c0, w) in enumerate(_col_parts(L, mp.in0_tiles)):
+            # input activation of this layer for the a-bar term
+            if l == 0 or (L.skip_tile >= 0 and pi == 1):
+                y2, y2_ld = ('ws', woff['IN0']), 16 * mp.in0_tiles
+            else:
+                Lp = P.layer[l - 1]
+                y2, y2_ld = ('ws', woff['H'] + Lp.hpre * P_pad), 16 * Lp.ot
+            nterms = 1 if last else 2
+            part = prog.alloc(nterms * S * wx * w)
+            t2 = part
+            if not last:
+                pm = ('ws', woff['PM'] + L.hpre * P_pad)
+                qb = ('ws', woff['QB'] + L.qpre * P_pad + c0)
+                prog.add_item(pm, x_ld, wx, qb, 16 * L.kt, w, part)
+                t2 = part + S * wx * w
+            vrow_off, v = -1, None
+            if last:
+                # sdf row of the output layer: sum_p gsdf[p] h[p][:]  (+ colsum of QLAST below)
+                vrow_off = prog.alloc(2 * S * w)
+                v = ('ws', woff['GSDF'])
+                prog.add_item(('ws', woff['QLAST']), 16 * L.kt, w, None, 0, 0, 0, colsum_off=vrow_off + S * w)
+                prog.add_rule(vrow_off, 2 * S, 1, w, -1, cm_off, int(dW_off[l]), cols, scale,
+                              fixed_row=int(mp.rowmaps[l][1][P.sdf_slot]))
+            prog.add_item(ab, x_ld, wx, y2, y2_ld, w, t2, colsum_off=(colsum_off if pi == 0 else -1),
+                          v=v, vrow_off=vrow_off)
+            prog.add_rule(part, nterms * S, wx, w, rm_off, cm_off + c0, int(dW_off[l]), cols, scale)
+        prog.add_rule(colsum_off, S, wx, 1, rm_off, -1, int(dB_off[l]), 1, 1.0)
+        if last:
+            # bias of the sdf row: column sums of the sdf tile of a-bar
+            cs = prog.alloc(S * 16)
+            prog.add_item(('ws', woff['AB'] + L.abpre * P_pad + 16 * P.feat_tiles), x_ld, 16, None, 0, 0, 0,
+                          colsum_off=cs)
+            prog.add_rule(cs, S, 16, 1, rm_off + 16 * P.feat_tiles, -1, int(dB_off[l]), 1, 1.0)
+    return prog
+
+
+def build_color_wgrad(mp, P_pad, n_splits):
+    """Items/rules for the colour network.  Buffers: 'ws' (colour workspace) and 'feat' (SDF features)."""
+    P = mp.plan
+    nu = P.n_layers
+    S = n_splits
+    woff, _ = color_workspace(mp, P_pad)
+    prog = WgradProgram(S)
+    dW_off, dB_off = mp.w_offsets, mp.b_offsets + mp.n_w
+    # first layer: units 0 (feature columns) and 1 (misc columns) share a-bar_0
+    for u in range(nu):
+        L = P.layer[u]
+        widx = mp.unit_weight[u]
+        rows, cols = mp.w_shapes[widx]
+        wx = 16 * L.ot
+        ab = ('ws', woff['AB'] + L.abpre * P_pad)
+        if u == 0:
+            y, y_ld = ('feat', 0), 16 * L.kt
+        elif u == 1:
+            y, y_ld = ('ws', woff['MISC']), 16 * mp.misc_tiles
+        else:
+            y, y_ld = ('ws', woff['H'] + L.hpre * P_pad), 16 * L.kt
+        w = 16 * L.kt
+        part = prog.alloc(S * wx * w)
+        cs = -1
+        if u != 1:
+            cs = prog.alloc(S * wx)
+        prog.add_item(ab, wx, wx, y, y_ld, w, part, colsum_off=cs)
+        prog.add_rule(part, S, wx, w, mp.rowmaps[u][0], mp.colmaps[u][0], int(dW_off[widx]), cols, 1.0)
+        if cs >= 0:
+            prog.add_rule(cs, S, wx, 1, mp.rowmaps[u][0], -1, int(dB_off[widx]), 1, 1.0)
+    return prog
