@@ -1,0 +1,196 @@
+"""bench.py -- rays/sec of the SDF volume-rendering training step (fwd + loss + bwd + Adam) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload = BASELINE.json configs[1]: 1024 rays x 98 samples per GPU, ImplicitNetwork 8x256
+(multires 6, skip [4], weight-norm, geometric init) + RenderingNetwork 289-256-256-3, error-bounded
+sampler 64/128/32; synthetic rays (origins U(-0.2,0.2)^3, unit directions) and random-init weights.
+Weak scaling: every rank renders its own 1024-ray batch, gradients are averaged with one RCCL
+all-reduce of the flat 2.7 MB gradient, as the reference's DDP does.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed inside the timed
+region) and `cpu_baseline` (the CPU oracle on a bounded sample, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_RAYS = 1024
+F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+
+
+def model_conf(width=256, depth=8):
+    from monosdf_amd.conf import ConfigTree
+    skip = [4] if depth > 4 else []
+    return ConfigTree.from_dict(dict(
+        feature_vector_size=width, scene_bounding_sphere=1.1, Grid_MLP=False,
+        implicit_network=dict(d_in=3, d_out=1, dims=[width] * depth, geometric_init=True, bias=0.9, skip_in=skip,
+                              weight_norm=True, multires=6, inside_outside=True),
+        rendering_network=dict(mode='idr', d_in=9, d_out=3, dims=[width, width], weight_norm=True,
+                               multires_view=4, per_image_code=False),
+        density=dict(params_init=dict(beta=0.1), beta_min=0.0001),
+        ray_sampler=dict(near=0.0, N_samples=64, N_samples_eval=128, N_samples_extra=32, eps=0.1, beta_iters=10,
+                         max_total_iters=5)))
+
+
+def make_rays(n, seed, device):
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(-0.2, 0.2, size=(n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    pose = np.tile(np.eye(4, dtype=np.float32), (n, 1, 1))
+    t = lambda a: torch.from_numpy(a).to(device)
+    return {'ray_dirs': t(d), 'ray_cam_loc': t(o), 'ray_dirs_tmp': t(d.copy()), 'ray_pose': t(pose)}
+
+
+def probe_loss(out):
+    """mean|rgb| + 0.05 eikonal + 0.05 mean|normal| + 0.1 mean depth + 0.005 smooth."""
+    loss = out['rgb_values'].abs().mean() + 0.05 * out['normal_map'].abs().mean() + 0.1 * out['depth_values'].mean()
+    g1, g2 = out['grad_theta'], out['grad_theta_nei']
+    loss = loss + 0.05 * ((g1.norm(2, dim=1) - 1) ** 2).mean()
+    n1 = g1 / (g1.norm(2, dim=1).unsqueeze(-1) + 1e-5)
+    n2 = g2 / (g2.norm(2, dim=1).unsqueeze(-1) + 1e-5)
+    return loss + 0.005 * torch.norm(n1 - n2, dim=-1).mean()
+
+
+def sdf_macs_per_point():
+    """F_sdf = 39*256 + 2*256^2 + 256*217 + 4*256^2 + 256*257 = 524,544 MAC."""
+    return 39 * 256 + 2 * 256 * 256 + 256 * 217 + 4 * 256 * 256 + 256 * 257
+
+
+def cpu_baseline(n_rays=256, iters=2):
+    """The CPU oracle (a port of the reference's PyTorch path, pinned by tests/golden) on a bounded sample."""
+    from oracle import config, monosdf_oracle as mo, synth
+    conf = config.mlp_config()
+    state = synth.make_state(conf, seed=0)
+    rays = synth.make_rays(n_rays, seed=1)
+    noise = synth.make_noise(conf, n_rays, 128, seed=2)
+    idx = torch.arange(n_rays)
+    times = []
+    for it in range(iters + 1):
+        st = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in state.items()}
+        t0 = time.time()
+        out = mo.render(st, conf, rays, idx, True, True, noise)
+        mo.probe_loss(out).backward()
+        times.append(time.time() - t0)
+    dt = float(np.mean(times[1:]))
+    return {'value': n_rays / dt, 'unit': 'rays/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '%d rays x 98 samples, fwd+bwd, %d timed iterations after 1 warm-up, fp32 PyTorch CPU oracle'
+                      % (n_rays, iters)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend='nccl', init_method='env://')
+
+    from monosdf_amd import _lib
+    from monosdf_amd.model.network import MonoSDFNetwork
+
+    torch.manual_seed(0)                      # same initial weights on every rank (as DDP would broadcast)
+    model = MonoSDFNetwork(model_conf()).to(device).train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=5e-4)
+    torch.manual_seed(1234 + rank)            # per-rank sampling noise
+    rays = make_rays(N_RAYS, 1 + rank, device)
+    indices = torch.arange(N_RAYS, device=device)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = model(rays, indices, if_pixel_input=True)
+        loss = probe_loss(out)
+        loss.backward()
+        if world > 1:
+            flat = torch.cat([p.grad.reshape(-1) for p in params])
+            dist.all_reduce(flat)
+            flat /= world
+            off = 0
+            for p in params:
+                p.grad.copy_(flat[off:off + p.numel()].view_as(p.grad))
+                off += p.numel()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    rounds = model.ray_sampler.last_rounds
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    _lib.PROFILE = {}
+    barrier()
+    t0 = time.time()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.time() - t0
+    prof, _lib.PROFILE = _lib.PROFILE, None
+    if world > 1:
+        t = torch.tensor([dt], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        # per-entry-point device time (HIP events on the launch stream, inside the timed region)
+        kern = {}
+        for name, evs in prof.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            kern[name] = {'launches_per_step': len(ms) / args.steps, 'avg_ms': float(np.mean(ms)),
+                          'ms_per_step': float(np.sum(ms)) / args.steps}
+        P_main, P_eik, P_smp = N_RAYS * 98, 4 * N_RAYS, N_RAYS * 128
+        F = sdf_macs_per_point()
+        flops = {   # algorithmic FLOPs per launch (2 FLOP / MAC), SURVEY.md 8(d) multipliers
+            'msdf_sdf_forward': 2.0 * F * P_smp,                 # no-grad forward, 1 x F_sdf
+            'msdf_sdf_fwd_grad': 2.0 * 2 * F * (P_main + P_eik),   # forward + d/dx sweep
+            'msdf_sdf_backward': 2.0 * 2 * F * (P_main + P_eik),   # p-bar = W q-bar and h-bar = W^T a-bar sweeps
+        }
+        dom = max((n for n in kern if n in flops), key=lambda n: kern[n]['ms_per_step'])
+        achieved = flops[dom] / (kern[dom]['avg_ms'] * 1e-3) / 1e12
+        res = {
+            'metric': 'rays/sec fwd+bwd, 1024 rays x 98 samples, 8x256 SDF MLP',
+            'value': world * N_RAYS * args.steps / dt, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'configs[1]: 1024 rays x 98 samples per GPU, ImplicitNetwork 8x256 + '
+                                   'RenderingNetwork 289-256-256-3, error-bounded sampler (k=%d round), '
+                                   'training step = fwd + loss + bwd + Adam' % rounds,
+                       'rays_per_gpu': N_RAYS, 'samples_per_ray': 98, 'sampler_rounds': rounds},
+            'roofline': {'bound': 'mfma', 'kernel': dom, 'achieved': achieved, 'peak': F32_MFMA_PEAK_TFLOPS,
+                         'unit': 'TFLOP/s', 'frac': achieved / F32_MFMA_PEAK_TFLOPS, 'traffic': None,
+                         'avg_kernel_ms': kern[dom]['avg_ms']},
+            'kernels_ms_per_step': {k: round(v['ms_per_step'], 4) for k, v in sorted(kern.items())},
+            'loss': float(loss.item()),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

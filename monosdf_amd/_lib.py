@@ -157,8 +157,21 @@ def exported_symbols():
     return sorted(_SIGNATURES)
 
 
+# bench.py sets this to a dict to collect (start, end) HIP events per entry point; they are recorded on
+# PyTorch's current stream, which is the stream every kernel is launched on (stream_ptr()).
+PROFILE = None
+
+
 def call(name, *args):
+    prof = PROFILE
+    if prof is not None:
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     status = getattr(load(), name)(*args)
+    if prof is not None:
+        e1.record()
+        prof.setdefault(name, []).append((e0, e1))
     if status != 0:
         raise RuntimeError('%s failed: %s' % (name, _ERR.get(status, 'status %d' % status)))
 

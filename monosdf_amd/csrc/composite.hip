@@ -19,6 +19,16 @@ __device__ __forceinline__ float wave_incl_scan(float v) {
   return v;
 }
 
+// exclusive prefix sum; `total` = sum over the wave.  (inclusive - self would cancel catastrophically
+// against the 1e10 * sigma free energy of the last interval)
+__device__ __forceinline__ float wave_excl_scan(const float v, float& total) {
+  float prev = __shfl_up(v, 1, 64);
+  if (lane_id() == 0) prev = 0.f;
+  const float ex = wave_incl_scan(prev);
+  total = __shfl(ex, 63, 64) + __shfl(v, 63, 64);
+  return ex;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
@@ -54,9 +64,10 @@ msdf_composite_forward_k(const CompositeArgs a) {
       const float dist = (i + 1 < S) ? (z[i + 1] - zi) : 1e10f;
       fe = dist * laplace_density(sd[i], beta);
     }
-    const float incl = wave_incl_scan(fe);
+    float chunk_total;
+    const float ex = wave_excl_scan(fe, chunk_total);
     if (ok) {
-      const float excl = carry + incl - fe;
+      const float excl = carry + ex;
       const float alpha = 1.0f - expf(-fe);
       const float trans = expf(-excl);
       w = alpha * trans;
@@ -69,7 +80,7 @@ msdf_composite_forward_k(const CompositeArgs a) {
       const float nn = sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]) + 1e-6f;
       m0 += w * (n[0] / nn); m1 += w * (n[1] / nn); m2 += w * (n[2] / nn);
     }
-    carry += __shfl(incl, 63, 64);
+    carry += chunk_total;
   }
   r0 = wave_sum(r0); r1 = wave_sum(r1); r2 = wave_sum(r2);
   wz = wave_sum(wz); ws = wave_sum(ws);
@@ -144,9 +155,10 @@ msdf_composite_backward_k(const CompositeBwdArgs a) {
         dist = (i + 1 < S) ? (z[i + 1] - zi) : 1e10f;
         fe = dist * laplace_density(sd[i], beta);
       }
-      const float incl = wave_incl_scan(fe);
+      float chunk_total;
+      const float ex = wave_excl_scan(fe, chunk_total);
       if (ok) {
-        const float excl = carry + incl - fe;
+        const float excl = carry + ex;
         const float trans = expf(-excl);
         const float w = a.weights[(size_t)ray * S + i];
         const float* c = a.rgb + ((size_t)ray * S + i) * 3;
@@ -166,7 +178,7 @@ msdf_composite_backward_k(const CompositeBwdArgs a) {
         gn[2] = w * (gM2 / nn - n[2] * k);
         fe_[ch] = fe; tr_[ch] = trans; wb_[ch] = wbar; dist_[ch] = dist;
       }
-      carry += __shfl(incl, 63, 64);
+      carry += chunk_total;
     }
   }
   // pass 2 (last chunk to first): E-bar_i = alpha-bar_i e^{-E_i} + sum_{k>i} C-bar_k,  C-bar_k = -w-bar_k alpha_k T_k

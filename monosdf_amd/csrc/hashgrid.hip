@@ -47,7 +47,9 @@ __device__ __forceinline__ HgCell hg_locate(const float* __restrict__ inputs, co
   const float x = inputs[(size_t)b * 3 + 0], y = inputs[(size_t)b * 3 + 1], z = inputs[(size_t)b * 3 + 2];
   c.oob = (x < 0.f || x > 1.f || y < 0.f || y > 1.f || z < 0.f || z > 1.f);
   c.hsize = (uint32_t)(offsets[level + 1] - offsets[level]);
-  c.scale = exp2f((float)level * S) * (float)H - 1.0f;
+  // exp2f(level * S) as the correctly rounded float (device exp2f is only ~1 ulp; one ulp of scale moves a
+  // fine-level sample by 1e-4 of a cell)
+  c.scale = (float)exp2((double)((float)level * S)) * (float)H - 1.0f;
   c.res = (uint32_t)ceilf(c.scale) + 1u;
   float px = x * c.scale, py = y * c.scale, pz = z * c.scale;
   const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);

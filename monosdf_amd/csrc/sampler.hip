@@ -229,10 +229,13 @@ __global__ void __launch_bounds__(64 * SMP_WAVES) smp_resample_k(const SmpArgs a
       fe = d * smp_density(l.sdf[i], beta);
       if (more && i + 1 < M) er = expf(-l.dstar[i] / beta) * (l.dist[i] * l.dist[i]) * inv4b2;
     }
-    const float fe_incl = smp_scan_incl(fe);
+    float fprev = __shfl_up(fe, 1, 64);
+    if (lane == 0) fprev = 0.f;
+    const float fe_excl = smp_scan_incl(fprev);
+    const float fe_incl = fe_excl + fe;
     const float er_incl = smp_scan_incl(er);
     if (ok && i + 1 < M) {
-      const float trans = expf(-(carry_fe + fe_incl - fe));
+      const float trans = expf(-(carry_fe + fe_excl));
       float p;
       if (more) p = (fminf(expf(carry_err + er_incl), 1.0e6f) - 1.0f) * trans + a.add_tiny;
       else p = (1.0f - expf(-fe)) * trans + 1e-5f;

@@ -207,8 +207,8 @@ msdf_sdf_fwd_grad_k(const msdf_plan_t plan, const FgArgs a) {
         if (t < in0_tiles) *(v4f*)(a.IN0 + (size_t)c.pt * (16 * in0_tiles) + 16 * t + 4 * c.q) = in0[t];
     }
   }
-  const int tile_base = blockIdx.x * MLP_PTS_PER_WG + (threadIdx.x >> 6) * MLP_PTS_PER_WAVE;
-  const bool want_feat = tile_base < a.n_feat;
+  // workgroup-uniform on purpose: the gemm below contains barriers and cooperative weight staging
+  const bool want_feat = blockIdx.x * MLP_PTS_PER_WG < a.n_feat;
 
   // ---------------- forward chain ----------------
   for (int l = 0; l < nl - 1; ++l) {

@@ -74,7 +74,7 @@ class HashEncoder(nn.Module):
         """sum_{l,c} d_out[b, l*C+c] * d enc[b,l,c] / d x01 (differentiable: second-order terms flow)."""
         inputs01, dy_dx, dims = handle
         B, D, C, L, S, H = dims
-        g = d_out.view(B, L, C).permute(1, 0, 2).contiguous()
+        g = d_out.reshape(B, L, C).permute(1, 0, 2).contiguous()
         g_in, _ = ops.HashEncodeBackwardFunction.apply(g, inputs01, self.embeddings, self.offsets, dy_dx, dims, True,
                                                        False)
         return g_in

@@ -135,13 +135,22 @@ class _SdfBase(_FusedNet):
         aux, handle = None, None
         if self.aux_active:
             aux, handle = self.encoding.encode_with_jacobian((x / self.divide_factor + 1.0) / 2.0)
+            aux = self._pad_aux(aux)
         radius = self.sdf_bounding_sphere if self.clamps else 0.0
         sdf, feat, nrm, r_aux = ops.SdfMlpFunction.apply(x, aux, flat_w, flat_b, wpack, bpack, fused, int(n_clamp),
                                                          int(n_feat), radius, self.sphere_scale, bool(save))
         if self.aux_active:
             # chain rule through x01 = (x / divide_factor + 1) / 2
+            r_aux = r_aux[:, :self.aux_cols]
             nrm = nrm + self.encoding.input_gradient(handle, r_aux) * (0.5 / self.divide_factor)
         return sdf, feat, nrm
+
+    def _pad_aux(self, aux):
+        """The kernels read whole 16-slot tiles of grid features."""
+        pad = (-aux.shape[1]) % 16
+        if pad:
+            aux = torch.nn.functional.pad(aux, (0, pad))
+        return aux.contiguous()
 
     def gradient_sdf(self, x):
         return self.evaluate(x, 0, 0)[2]
@@ -155,7 +164,7 @@ class _SdfBase(_FusedNet):
         aux = None
         if self.aux_active:
             with torch.no_grad():
-                aux = self.encoding((x / self.divide_factor).detach(), calc_grad_inputs=False).contiguous()
+                aux = self._pad_aux(self.encoding((x / self.divide_factor).detach(), calc_grad_inputs=False))
         radius = self.sdf_bounding_sphere if self.clamps else 0.0
         return ops.sdf_forward_nograd(fused, wpack, bpack, x.detach(), aux, radius, self.sphere_scale)
 

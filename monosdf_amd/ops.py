@@ -115,7 +115,11 @@ class SdfMlpFunction(torch.autograd.Function):
         ws = torch.empty(max(total, 64), device=dev, dtype=torch.float32)
         F = 16 * plan.feat_tiles
         sdf = torch.empty(P, 1, device=dev, dtype=torch.float32)
-        feat = torch.empty(n_feat, F, device=dev, dtype=torch.float32)
+        # rows up to the next multiple of 64 exist (zero) so the colour network's weight-gradient GEMM
+        # can stream whole 64-point tiles of this buffer
+        feat_full = torch.empty(_pad64(max(n_feat, 1)), F, device=dev, dtype=torch.float32)
+        feat_full[n_feat:].zero_()
+        feat = feat_full[:n_feat]
         nrm = torch.empty(P, 3, device=dev, dtype=torch.float32)
         r_aux = torch.empty(P, 16 * plan.aux_tiles, device=dev, dtype=torch.float32) if has_aux else None
         clamped = torch.empty(max(P, 1), device=dev, dtype=torch.uint8)
@@ -194,6 +198,12 @@ class ColorMlpFunction(torch.autograd.Function):
         dev = x.device
         if feat.shape[1] != 16 * plan.layer[0].kt:
             raise RuntimeError('monosdf_amd: feature width must be a multiple of 16')
+        room = feat.untyped_storage().nbytes() // 4 - feat.storage_offset()
+        if room < P_pad * feat.shape[1]:
+            # the weight-gradient GEMM streams whole 64-point tiles: give the tail rows finite values
+            padded = torch.zeros(P_pad, feat.shape[1], device=dev, dtype=torch.float32)
+            padded[:P] = feat
+            feat = padded[:P]
         has_code = plan.aux_tiles > 0
         if has_code:
             code = _need_cuda(code.detach(), 'image code')

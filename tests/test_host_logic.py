@@ -1,0 +1,179 @@
+"""CPU tests of the host side: ABI surface, plan / slot maps, workspace + weight-gradient programs,
+state-dict compatibility.  No GPU compute is called here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import Case
+from oracle import config, monosdf_oracle as mo, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'monosdf_hip.h')).read()
+    return sorted(set(re.findall(r'^int (msdf_\w+)\(', text, flags=re.M)))
+
+
+def test_header_and_binding_agree():
+    from monosdf_amd import _lib
+    assert _declared_symbols() == _lib.exported_symbols()
+
+
+def test_library_exports_every_declared_symbol():
+    from monosdf_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip('library not built (run python __graft_entry__.py)')
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in _declared_symbols():
+        assert hasattr(lib, name), name
+    assert lib.msdf_abi_version() == 1
+
+
+def test_struct_sizes_match_header():
+    """ctypes mirrors of the C structs must have the C compiler's layout."""
+    import subprocess, tempfile
+    from monosdf_amd import _lib
+    names = {'msdf_plan_t': _lib.Plan, 'msdf_layer_t': _lib.Layer, 'msdf_packrule_t': _lib.PackRule,
+             'msdf_wgrad_item_t': _lib.WgradItem, 'msdf_reduce_rule_t': _lib.ReduceRule,
+             'msdf_fg_args_t': _lib.FgArgs, 'msdf_bw_args_t': _lib.BwArgs,
+             'msdf_color_fwd_args_t': _lib.ColorFwdArgs, 'msdf_color_bwd_args_t': _lib.ColorBwdArgs,
+             'msdf_composite_args_t': _lib.CompositeArgs, 'msdf_composite_bwd_args_t': _lib.CompositeBwdArgs,
+             'msdf_sampler_args_t': _lib.SamplerArgs}
+    src = '#include <stdio.h>\n#include "monosdf_hip.h"\nint main(){' + ''.join(
+        'printf("%s %%zu\\n", sizeof(%s));' % (n, n) for n in names) + 'return 0;}'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, 't.c'), 'w').write(src)
+        subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), os.path.join(d, 't.c'), '-o',
+                               os.path.join(d, 't')])
+        out = subprocess.check_output([os.path.join(d, 't')]).decode().split()
+    sizes = dict(zip(out[::2], map(int, out[1::2])))
+    for n, cls in names.items():
+        assert ctypes.sizeof(cls) == sizes[n], (n, ctypes.sizeof(cls), sizes[n])
+
+
+def _slot_forward(mp, weights, biases, x, aux=None):
+    """Numpy emulation of the kernels' slot-space forward (maps + scale only, no tiling)."""
+    P = mp.plan
+    n = P.n_layers
+    pe = mo.positional_encoding(torch.from_numpy(x), P.n_freqs).numpy()
+    in0 = np.zeros((x.shape[0], 16 * mp.in0_tiles))
+    in0[:, :pe.shape[1]] = pe
+    if aux is not None:
+        in0[:, 48:48 + aux.shape[1]] = aux
+    h = in0
+    for l in range(n):
+        L = P.layer[l]
+        rm, cm = mp.rowmaps[l][1], mp.colmaps[l][1]
+        if L.skip_tile >= 0:
+            h = np.concatenate([h[:, :16 * L.skip_tile], in0], 1)
+        W = np.zeros((len(rm), len(cm)))
+        b = np.zeros(len(rm))
+        for i, r in enumerate(rm):
+            if r < 0:
+                continue
+            b[i] = biases[l][r]
+            ok = cm >= 0
+            W[i, ok] = weights[l][r, cm[ok]] * mp.rules[l].scale
+        a = h[:, :len(cm)] @ W.T + b
+        h = np.log1p(np.exp(np.minimum(100 * a, 50))) / 100 if l < n - 1 else a
+        if l < n - 1:
+            h = np.where(100 * a > 20, a, h)
+    return h
+
+
+@pytest.mark.parametrize('kind,width', [('mlp', 64), ('mlp', 256), ('gridless', 128)])
+def test_sdf_plan_slot_maps_reproduce_the_network(kind, width):
+    from monosdf_amd import plan as planlib
+    conf = config.mlp_config(width) if kind == 'mlp' else config.gridless_config(width)
+    st = synth.make_state(conf, seed=0, jitter=0.3, dtype=torch.float64)
+    ic = conf['implicit_network']
+    n = len(ic['dims']) + 1
+    Ws = [mo.effective_weight(st, 'implicit_network.lin%d' % l).numpy() for l in range(n)]
+    bs = [st['implicit_network.lin%d.bias' % l].numpy() for l in range(n)]
+    aux_cols = 32 if kind == 'gridless' else 0
+    mp = planlib.build_sdf_plan([w.shape for w in Ws], ic['skip_in'], ic['multires'], aux_cols, False, width)
+    x = np.random.default_rng(0).normal(size=(50, 3)) * 0.6
+    out = _slot_forward(mp, Ws, bs, x)
+    ref = mo.sdf_network_raw(st, conf, torch.from_numpy(x)).numpy()
+    P = mp.plan
+    assert np.allclose(out[:, P.sdf_slot], ref[:, 0], atol=1e-6)
+    assert np.allclose(out[:, :width], ref[:, 1:], atol=1e-6)
+    # padded K only ever pads with tiles that map to -1
+    for l in range(P.n_layers):
+        L = P.layer[l]
+        assert L.ktp >= L.kt and L.otp >= L.ot and L.kt <= 17 and L.ot <= 17
+
+
+def test_wgrad_program_covers_every_weight_once():
+    from monosdf_amd import plan as planlib
+    shapes = [(256, 39), (256, 256), (256, 256), (217, 256), (256, 256), (256, 256), (256, 256), (256, 256),
+              (257, 256)]
+    mp = planlib.build_sdf_plan(shapes, [4], 6, 0, False, 256)
+    prog = planlib.build_sdf_wgrad(mp, 128, 2)
+    cover = np.zeros(mp.n_w + mp.n_b, dtype=np.int32)
+    maps = mp.maps_np
+    for r in prog.rules:
+        for i in range(r.wx):
+            row = maps[r.rowmap_off + i] if r.rowmap_off >= 0 else r.fixed_row
+            if row < 0:
+                continue
+            for j in range(r.wy):
+                col = maps[r.colmap_off + j] if r.colmap_off >= 0 else 0
+                if col >= 0:
+                    cover[r.dst_off + row * r.dst_ld + col] += 1
+    assert cover.min() == 1 and cover.max() == 1
+    # partial blocks do not overlap
+    spans = []
+    for it in prog.items:
+        if it['wy'] > 0:
+            spans.append((it['part_off'], it['part_off'] + prog.n_splits * it['wx'] * it['wy']))
+        if it['colsum_off'] >= 0:
+            spans.append((it['colsum_off'], it['colsum_off'] + prog.n_splits * it['wx']))
+        if it['vrow_off'] >= 0:
+            spans.append((it['vrow_off'], it['vrow_off'] + prog.n_splits * it['wy']))
+    spans.sort()
+    for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+        assert a1 <= b0
+    assert spans[-1][1] <= prog.part_f
+
+
+def test_color_wgrad_program_covers_every_weight_once():
+    from monosdf_amd import plan as planlib
+    mp = planlib.build_color_plan([(256, 289 + 32), (256, 256), (3, 256)], 'idr', 4, 256, code_cols=32)
+    prog = planlib.build_color_wgrad(mp, 128, 2)
+    cover = np.zeros(mp.n_w + mp.n_b, dtype=np.int32)
+    maps = mp.maps_np
+    for r in prog.rules:
+        for i in range(r.wx):
+            row = maps[r.rowmap_off + i]
+            if row < 0:
+                continue
+            for j in range(r.wy):
+                col = maps[r.colmap_off + j] if r.colmap_off >= 0 else 0
+                if col >= 0:
+                    cover[r.dst_off + row * r.dst_ld + col] += 1
+    assert cover.min() == 1 and cover.max() == 1
+
+
+def test_state_dict_is_interchangeable_with_the_reference_layout():
+    """Keys / shapes of our modules equal the reference's (golden synth states use the reference's key names)."""
+    from monosdf_amd.conf import ConfigTree
+    from monosdf_amd.model.network import MonoSDFNetwork
+    for name in ['mlp_w64_eval', 'gridless_w128_train', 'grid_small_eval', 'mlp_w64_code_train']:
+        c = Case(name)
+        m = MonoSDFNetwork(ConfigTree.from_dict(c.conf))
+        m.load_state_dict(c.state, strict=True)
+        assert set(m.state_dict()) == set(c.state)
+
+
+def test_cpu_tensors_fail_loudly():
+    from monosdf_amd.conf import ConfigTree
+    from monosdf_amd.model.network import MonoSDFNetwork
+    m = MonoSDFNetwork(ConfigTree.from_dict(config.mlp_config(64)))
+    with pytest.raises(RuntimeError):
+        m.implicit_network.get_outputs(torch.zeros(4, 3))
