@@ -66,6 +66,8 @@ typedef struct {
   int64_t vrow_off;             /* [n_splits][wy] or < 0 */
   int32_t x_ld, y_ld;           /* row pitches of X and Y */
   int32_t wx, wy;               /* multiples of 16, <= 256; wy == 0: column sums only */
+  int32_t n_splits;             /* this item's share of the points is cut into n_splits workgroups */
+  int32_t pad_;
 } msdf_wgrad_item_t;
 
 /* one reduction rule: dst[rowmap[i]*dst_ld + colmap[j]] = scale * sum_b PART[b][i*wy + j] */

@@ -102,11 +102,20 @@ msdf_composite_forward_k(const CompositeArgs a) {
 
 typedef msdf_composite_bwd_args_t CompositeBwdArgs;
 
-// suffix sum (exclusive) helper: sum of v over lanes > lane
-__device__ __forceinline__ float wave_excl_suffix(float v, float& total) {
-  const float incl = wave_incl_scan(v);
-  total = __shfl(incl, 63, 64);
-  return total - incl;
+// exclusive suffix sum: sum of v over lanes > lane; `total` = sum over the wave.  Built from a shifted
+// reverse scan so that a lane with nothing after it gets EXACTLY 0 (total - inclusive would leave
+// rounding noise, which the 1e10 last-interval length then multiplies into the sdf / beta gradients).
+__device__ __forceinline__ float wave_excl_suffix(const float v, float& total) {
+  const int lane = lane_id();
+  float s = __shfl_down(v, 1, 64);
+  if (lane == 63) s = 0.f;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float o = __shfl_down(s, d, 64);
+    if (lane + d < 64) s += o;
+  }
+  total = __shfl(s, 0, 64) + __shfl(v, 0, 64);
+  return s;
 }
 
 __global__ void __launch_bounds__(256)

@@ -37,11 +37,12 @@ __device__ __forceinline__ void wg_issue_tile(const float* __restrict__ src, con
 }
 
 __global__ void __launch_bounds__(WG_THREADS, 2)
-msdf_wgrad_k(const msdf_wgrad_item_t* __restrict__ items, const float* __restrict__ ws,
-                  float* __restrict__ part, const int P_pad, const int n_splits) {
+msdf_wgrad_k(const msdf_wgrad_item_t* __restrict__ items, const int* __restrict__ wg_map,
+                  const float* __restrict__ ws, float* __restrict__ part, const int P_pad) {
   extern __shared__ float lds_f[];
-  const msdf_wgrad_item_t it = items[blockIdx.y];
-  const int split = blockIdx.x;
+  const msdf_wgrad_item_t it = items[wg_map[2 * blockIdx.x]];
+  const int split = wg_map[2 * blockIdx.x + 1];
+  const int n_splits = it.n_splits;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -161,16 +162,15 @@ msdf_reduce_k(const msdf_reduce_rule_t* __restrict__ rules, const int* __restric
   }
 }
 
-extern "C" int msdf_wgrad(const msdf_wgrad_item_t* items_dev, int n_items, const float* workspace, float* partials,
-                          int P_pad, int n_splits, void* stream) {
-  if (n_items < 0 || n_splits < 1 || P_pad < 0 || (P_pad % WG_NP) != 0) return MSDF_ERR_ARG;
-  if (n_items == 0 || P_pad == 0) return MSDF_OK;
+extern "C" int msdf_wgrad(const msdf_wgrad_item_t* items_dev, const int32_t* wg_map_dev, int n_wgs,
+                          const float* workspace, float* partials, int P_pad, void* stream) {
+  if (n_wgs < 0 || P_pad < 0 || (P_pad % WG_NP) != 0) return MSDF_ERR_ARG;
+  if (n_wgs == 0 || P_pad == 0) return MSDF_OK;
   if (hipFuncSetAttribute((const void*)msdf_wgrad_k, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS_BYTES) !=
       hipSuccess)
     return MSDF_ERR_LAUNCH;
-  const dim3 grid(n_splits, n_items);
-  msdf_wgrad_k<<<grid, WG_THREADS, WG_LDS_BYTES, (hipStream_t)stream>>>(items_dev, workspace, partials, P_pad,
-                                                                         n_splits);
+  msdf_wgrad_k<<<n_wgs, WG_THREADS, WG_LDS_BYTES, (hipStream_t)stream>>>(items_dev, wg_map_dev, workspace,
+                                                                          partials, P_pad);
   return msdf_check_launch();
 }
 

@@ -35,7 +35,6 @@ class FusedMlp:
         self.rules_dev = torch.from_numpy(mlp_plan.rules_np).to(device)
         self.maps_dev = torch.from_numpy(mlp_plan.maps_np).to(device)
         self._wgrad_cache = {}
-        self.n_splits = 32
 
     # -- weights -----------------------------------------------------------------
     def pack(self, flat_w, flat_b):
@@ -53,11 +52,11 @@ class FusedMlp:
     def wgrad_program(self, P_pad):
         key = P_pad
         if key not in self._wgrad_cache:
-            n_splits = max(1, min(self.n_splits, P_pad // 32))
             build = planlib.build_sdf_wgrad if self.mp.kind == 'sdf' else planlib.build_color_wgrad
-            prog = build(self.mp, P_pad, n_splits)
+            prog = planlib.balanced_program(build, self.mp, P_pad)
             rules_dev = torch.from_numpy(prog.rules_bytes()).to(self.device)
-            self._wgrad_cache[key] = dict(prog=prog, rules=rules_dev, items={})
+            wg_map = torch.from_numpy(prog.wg_map()).to(self.device)
+            self._wgrad_cache[key] = dict(prog=prog, rules=rules_dev, wg_map=wg_map, items={})
         return self._wgrad_cache[key]
 
     def run_wgrad(self, P_pad, base_addr):
@@ -74,8 +73,9 @@ class FusedMlp:
         part = torch.empty(prog.part_f + 64, device=self.device, dtype=torch.float32)
         grad = torch.zeros(self.mp.n_w + self.mp.n_b, device=self.device, dtype=torch.float32)
         st = _lib.stream_ptr()
-        _lib.call('msdf_wgrad', _lib.ptr(items_dev), len(prog.items), None, _lib.ptr(part), P_pad,
-                  prog.n_splits, st)
+        wg_map = ent['wg_map']
+        _lib.call('msdf_wgrad', _lib.ptr(items_dev), _lib.ptr(wg_map), wg_map.numel() // 2, None, _lib.ptr(part),
+                  P_pad, st)
         _lib.call('msdf_reduce', _lib.ptr(ent['rules']), len(prog.rules), _lib.ptr(self.maps_dev),
                   _lib.ptr(part), _lib.ptr(grad), st)
         return grad

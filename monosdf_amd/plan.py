@@ -250,11 +250,13 @@ def color_workspace(mp, P_pad):
 # weight-gradient work items + reduction rules
 # ---------------------------------------------------------------------------
 class WgradProgram:
-    """Work items (with absolute device addresses filled in per call) and reduce rules."""
+    """Work items (absolute device addresses are filled in per call), reduce rules and the
+    workgroup -> (item, split) map.  Every item cuts its point range into its own number of splits,
+    chosen so that all workgroups of a launch run about equally long and fill the 256 CUs."""
 
-    def __init__(self, n_splits):
-        self.n_splits = n_splits
-        self.items = []      # dicts: x, y, v = (buffer name, float offset) ; part/colsum/vrow offsets
+    def __init__(self, split_fn):
+        self.split_fn = split_fn
+        self.items = []      # dicts: x, y, v = (buffer name, float offset); part/colsum/vrow offsets; n_splits
         self.rules = []      # ReduceRule
         self.part_f = 0
 
@@ -263,10 +265,23 @@ class WgradProgram:
         self.part_f += n
         return off
 
-    def add_item(self, x, x_ld, wx, y, y_ld, wy, part_off, colsum_off=-1, v=None, vrow_off=-1):
+    @staticmethod
+    def weight(wx, wy):
+        """Relative duration of one stage: 1 when both waves of a SIMD are busy, 0.5 when <= 4 of the
+        8 waves have a tile, 0 for column-sum-only items."""
+        if wy == 0:
+            return 0.0
+        active = min(2, (wx + 127) // 128) * min(4, (wy + 63) // 64)
+        return 1.0 if active > 4 else 0.5
+
+    def splits(self, wx, wy):
+        return self.split_fn(self.weight(wx, wy))
+
+    def add_item(self, x, x_ld, wx, y, y_ld, wy, part_off, n_splits, colsum_off=-1, v=None, vrow_off=-1):
         assert wx % 16 == 0 and wy % 16 == 0 and wx <= 256 and wy <= 256, (wx, wy)
         self.items.append(dict(x=x, y=y, v=v, x_ld=x_ld, y_ld=y_ld, wx=wx, wy=wy, part_off=part_off,
-                               colsum_off=colsum_off, vrow_off=vrow_off))
+                               colsum_off=colsum_off, vrow_off=vrow_off, n_splits=n_splits,
+                               weight=self.weight(wx, wy)))
 
     def add_rule(self, part_off, n_blocks, wx, wy, rowmap_off, colmap_off, dst_off, dst_ld, scale,
                  fixed_row=0):
@@ -277,6 +292,12 @@ class WgradProgram:
 
     def rules_bytes(self):
         return np.frombuffer(b''.join(bytes(r) for r in self.rules), dtype=np.uint8).copy()
+
+    def wg_map(self):
+        """int32 (item, split) pairs; long items first so the tail of the launch is made of short ones."""
+        order = sorted(range(len(self.items)), key=lambda i: -self.items[i]['weight'])
+        pairs = [(i, s) for i in order for s in range(self.items[i]['n_splits'])]
+        return np.asarray(pairs, dtype=np.int32).reshape(-1)
 
     def items_bytes(self, base_addr):
         """base_addr: dict buffer name -> absolute device address (bytes)."""
@@ -290,8 +311,32 @@ class WgradProgram:
             w.v_off = (base_addr[it['v'][0]] // 4 + it['v'][1]) if it['v'] is not None else -1
             w.part_off, w.colsum_off, w.vrow_off = it['part_off'], it['colsum_off'], it['vrow_off']
             w.x_ld, w.y_ld, w.wx, w.wy = it['x_ld'], it['y_ld'], it['wx'], it['wy']
+            w.n_splits = it['n_splits']
             out.append(bytes(w))
         return np.frombuffer(b''.join(out), dtype=np.uint8).copy()
+
+
+def balanced_program(build, mp, P_pad, n_cu=256, max_stages=256):
+    """Run `build` twice: once to count the items per duration class, once with split counts that make
+    (#workgroups) ~ k * n_cu with equally long workgroups (k as small as the stage cap allows)."""
+    n_stages = max(1, P_pad // 32)
+    probe = build(mp, P_pad, lambda w: 1)
+    n_big = sum(1 for it in probe.items if it['weight'] == 1.0)
+    n_half = sum(1 for it in probe.items if it['weight'] == 0.5)
+    n_tiny = sum(1 for it in probe.items if it['weight'] == 0.0)
+    units = n_big + 0.5 * n_half
+    S = 1
+    for k in range(1, 9):
+        S = int((k * n_cu - 2 * n_tiny) / max(units, 0.5))
+        if S >= 1 and (n_stages + S - 1) // S <= max_stages:
+            break
+    S = max(1, min(S, n_stages))
+
+    def split_fn(w):
+        if w == 0.0:
+            return min(2, n_stages)
+        return max(1, min(n_stages, int(round(S * w))))
+    return build(mp, P_pad, split_fn)
 
 
 def _col_parts(L, in0_tiles):
@@ -301,14 +346,13 @@ def _col_parts(L, in0_tiles):
     return [(0, 16 * L.kt)]
 
 
-def build_sdf_wgrad(mp, P_pad, n_splits):
+def build_sdf_wgrad(mp, P_pad, split_fn):
     """Items/rules of d W_l, d b_l for the SDF network.  Buffer names refer to the workspace
     ('ws', float offsets from sdf_workspace)."""
     P = mp.plan
     n = P.n_layers
-    S = n_splits
     woff, _ = sdf_workspace(mp, P_pad)
-    prog = WgradProgram(S)
+    prog = WgradProgram(split_fn)
     dW_off, dB_off = mp.w_offsets, mp.b_offsets + mp.n_w     # gradient buffer: all dW then all db
     for l in range(n):
         L = P.layer[l]
@@ -320,8 +364,11 @@ def build_sdf_wgrad(mp, P_pad, n_splits):
         wx = 16 * (P.feat_tiles if last else L.ot)
         x_ld = 16 * L.ot
         ab = ('ws', woff['AB'] + L.abpre * P_pad)
-        colsum_off = prog.alloc(S * wx)
-        for pi, (c0, w) in enumerate(_col_parts(L, mp.in0_tiles)):
+        parts = _col_parts(L, mp.in0_tiles)
+        S0 = prog.splits(wx, parts[0][1])               # splits of the item that also carries the bias sums
+        colsum_off = prog.alloc(S0 * wx)
+        for pi, (c0, w) in enumerate(parts):
+            S = prog.splits(wx, w)
             # input activation of this layer for the a-bar term
             if l == 0 or (L.skip_tile >= 0 and pi == 1):
                 y2, y2_ld = ('ws', woff['IN0']), 16 * mp.in0_tiles
@@ -334,36 +381,37 @@ def build_sdf_wgrad(mp, P_pad, n_splits):
             if not last:
                 pm = ('ws', woff['PM'] + L.hpre * P_pad)
                 qb = ('ws', woff['QB'] + L.qpre * P_pad + c0)
-                prog.add_item(pm, x_ld, wx, qb, 16 * L.kt, w, part)
+                prog.add_item(pm, x_ld, wx, qb, 16 * L.kt, w, part, S)
                 t2 = part + S * wx * w
             vrow_off, v = -1, None
             if last:
-                # sdf row of the output layer: sum_p gsdf[p] h[p][:]  (+ colsum of QLAST below)
-                vrow_off = prog.alloc(2 * S * w)
+                # sdf row of the output layer: sum_p gsdf[p] h[p][:]  (+ colsum of QLAST)
+                Sq = prog.splits(w, 0)
+                vrow_off = prog.alloc((S + Sq) * w)
                 v = ('ws', woff['GSDF'])
-                prog.add_item(('ws', woff['QLAST']), 16 * L.kt, w, None, 0, 0, 0, colsum_off=vrow_off + S * w)
-                prog.add_rule(vrow_off, 2 * S, 1, w, -1, cm_off, int(dW_off[l]), cols, scale,
+                prog.add_item(('ws', woff['QLAST']), 16 * L.kt, w, None, 0, 0, 0, Sq, colsum_off=vrow_off + S * w)
+                prog.add_rule(vrow_off, S + Sq, 1, w, -1, cm_off, int(dW_off[l]), cols, scale,
                               fixed_row=int(mp.rowmaps[l][1][P.sdf_slot]))
-            prog.add_item(ab, x_ld, wx, y2, y2_ld, w, t2, colsum_off=(colsum_off if pi == 0 else -1),
+            prog.add_item(ab, x_ld, wx, y2, y2_ld, w, t2, S, colsum_off=(colsum_off if pi == 0 else -1),
                           v=v, vrow_off=vrow_off)
             prog.add_rule(part, nterms * S, wx, w, rm_off, cm_off + c0, int(dW_off[l]), cols, scale)
-        prog.add_rule(colsum_off, S, wx, 1, rm_off, -1, int(dB_off[l]), 1, 1.0)
+        prog.add_rule(colsum_off, S0, wx, 1, rm_off, -1, int(dB_off[l]), 1, 1.0)
         if last:
             # bias of the sdf row: column sums of the sdf tile of a-bar
-            cs = prog.alloc(S * 16)
-            prog.add_item(('ws', woff['AB'] + L.abpre * P_pad + 16 * P.feat_tiles), x_ld, 16, None, 0, 0, 0,
+            Sc = prog.splits(16, 0)
+            cs = prog.alloc(Sc * 16)
+            prog.add_item(('ws', woff['AB'] + L.abpre * P_pad + 16 * P.feat_tiles), x_ld, 16, None, 0, 0, 0, Sc,
                           colsum_off=cs)
-            prog.add_rule(cs, S, 16, 1, rm_off + 16 * P.feat_tiles, -1, int(dB_off[l]), 1, 1.0)
+            prog.add_rule(cs, Sc, 16, 1, rm_off + 16 * P.feat_tiles, -1, int(dB_off[l]), 1, 1.0)
     return prog
 
 
-def build_color_wgrad(mp, P_pad, n_splits):
+def build_color_wgrad(mp, P_pad, split_fn):
     """Items/rules for the colour network.  Buffers: 'ws' (colour workspace) and 'feat' (SDF features)."""
     P = mp.plan
     nu = P.n_layers
-    S = n_splits
     woff, _ = color_workspace(mp, P_pad)
-    prog = WgradProgram(S)
+    prog = WgradProgram(split_fn)
     dW_off, dB_off = mp.w_offsets, mp.b_offsets + mp.n_w
     # first layer: units 0 (feature columns) and 1 (misc columns) share a-bar_0
     for u in range(nu):
@@ -379,11 +427,12 @@ def build_color_wgrad(mp, P_pad, n_splits):
         else:
             y, y_ld = ('ws', woff['H'] + L.hpre * P_pad), 16 * L.kt
         w = 16 * L.kt
+        S = prog.splits(wx, w)
         part = prog.alloc(S * wx * w)
         cs = -1
         if u != 1:
             cs = prog.alloc(S * wx)
-        prog.add_item(ab, wx, wx, y, y_ld, w, part, colsum_off=cs)
+        prog.add_item(ab, wx, wx, y, y_ld, w, part, S, colsum_off=cs)
         prog.add_rule(part, S, wx, w, mp.rowmaps[u][0], mp.colmaps[u][0], int(dW_off[widx]), cols, 1.0)
         if cs >= 0:
             prog.add_rule(cs, S, wx, 1, mp.rowmaps[u][0], -1, int(dB_off[widx]), 1, 1.0)

@@ -52,9 +52,13 @@ def level_geometry(ic):
 
 def level_scale(geo, level):
     """scale = exp2f(level*S)*H - 1 and resolution = ceil(scale)+1 in float32 (cu:152-153)."""
+    # exp2f evaluated as the correctly rounded float (double pow, then one rounding): numpy's float32
+    # exp2 and device exp2f are both only accurate to ~1 ulp and disagree with each other on some levels,
+    # and one ulp of scale moves a fine-level sample by ~1e-4 of a cell.
     s32 = np.float32(geo['S'])
-    scale = np.float32(np.exp2(np.float32(level) * s32)) * np.float32(geo['H']) - np.float32(1.0)
-    scale = np.float32(scale)
+    arg = np.float32(np.float32(level) * s32)
+    e = np.float32(2.0 ** float(arg))
+    scale = np.float32(np.float32(e * np.float32(geo['H'])) - np.float32(1.0))
     return float(scale), int(math.ceil(float(scale))) + 1
 
 

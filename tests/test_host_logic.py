@@ -114,7 +114,7 @@ def test_wgrad_program_covers_every_weight_once():
     shapes = [(256, 39), (256, 256), (256, 256), (217, 256), (256, 256), (256, 256), (256, 256), (256, 256),
               (257, 256)]
     mp = planlib.build_sdf_plan(shapes, [4], 6, 0, False, 256)
-    prog = planlib.build_sdf_wgrad(mp, 128, 2)
+    prog = planlib.balanced_program(planlib.build_sdf_wgrad, mp, 128)
     cover = np.zeros(mp.n_w + mp.n_b, dtype=np.int32)
     maps = mp.maps_np
     for r in prog.rules:
@@ -130,12 +130,13 @@ def test_wgrad_program_covers_every_weight_once():
     # partial blocks do not overlap
     spans = []
     for it in prog.items:
+        S = it['n_splits']
         if it['wy'] > 0:
-            spans.append((it['part_off'], it['part_off'] + prog.n_splits * it['wx'] * it['wy']))
+            spans.append((it['part_off'], it['part_off'] + S * it['wx'] * it['wy']))
         if it['colsum_off'] >= 0:
-            spans.append((it['colsum_off'], it['colsum_off'] + prog.n_splits * it['wx']))
+            spans.append((it['colsum_off'], it['colsum_off'] + S * it['wx']))
         if it['vrow_off'] >= 0:
-            spans.append((it['vrow_off'], it['vrow_off'] + prog.n_splits * it['wy']))
+            spans.append((it['vrow_off'], it['vrow_off'] + S * it['wy']))
     spans.sort()
     for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
         assert a1 <= b0
@@ -145,7 +146,7 @@ def test_wgrad_program_covers_every_weight_once():
 def test_color_wgrad_program_covers_every_weight_once():
     from monosdf_amd import plan as planlib
     mp = planlib.build_color_plan([(256, 289 + 32), (256, 256), (3, 256)], 'idr', 4, 256, code_cols=32)
-    prog = planlib.build_color_wgrad(mp, 128, 2)
+    prog = planlib.balanced_program(planlib.build_color_wgrad, mp, 128)
     cover = np.zeros(mp.n_w + mp.n_b, dtype=np.int32)
     maps = mp.maps_np
     for r in prog.rules:
