@@ -112,13 +112,19 @@ __device__ __forceinline__ void gemm_tiles(v4f (&acc)[MT], const v4f (&in)[MT], 
       const int o0 = 2 * c;
       const int o1 = (2 * c + 1 < MT) ? 2 * c + 1 : 0;   // the dead pair of the last odd tile
       if (2 * c + 1 < MT && 2 * c + 1 < OT) {
+        if (!DYN) {
+          // software-pipelined: the A fragments of k tile kt+1 are in flight while the 8 MFMAs of kt issue
+          v4f a0 = w0[0], a1 = w1[0];
+          v4f c0 = acc[o0], c1 = acc[o1];
 #pragma unroll
-        for (int kt = 0; kt < KMAX; ++kt) {
-          if (!DYN || kt < K) {
-            const v4f a0 = w0[kt * 64];
-            const v4f a1 = w1[kt * 64];
+          for (int kt = 0; kt < KMAX; ++kt) {
+            v4f n0 = a0, n1 = a1;
+            if (kt + 1 < KMAX) {
+              n0 = w0[(kt + 1) * 64];
+              n1 = w1[(kt + 1) * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch above the MFMAs
             const v4f b = in[kt];
-            v4f c0 = acc[o0], c1 = acc[o1];
             c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, c0, 0, 0, 0);
             c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b.x, c1, 0, 0, 0);
             c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, c0, 0, 0, 0);
@@ -127,14 +133,50 @@ __device__ __forceinline__ void gemm_tiles(v4f (&acc)[MT], const v4f (&in)[MT], 
             c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b.z, c1, 0, 0, 0);
             c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b.w, c0, 0, 0, 0);
             c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b.w, c1, 0, 0, 0);
-            acc[o0] = c0;
-            acc[o1] = c1;
+            a0 = n0;
+            a1 = n1;
+          }
+          acc[o0] = c0;
+          acc[o1] = c1;
+        } else {
+#pragma unroll
+          for (int kt = 0; kt < KMAX; ++kt) {
+            if (kt < K) {
+              const v4f a0 = w0[kt * 64];
+              const v4f a1 = w1[kt * 64];
+              const v4f b = in[kt];
+              v4f c0 = acc[o0], c1 = acc[o1];
+              c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, c0, 0, 0, 0);
+              c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b.x, c1, 0, 0, 0);
+              c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, c0, 0, 0, 0);
+              c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b.y, c1, 0, 0, 0);
+              c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b.z, c0, 0, 0, 0);
+              c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b.z, c1, 0, 0, 0);
+              c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b.w, c0, 0, 0, 0);
+              c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b.w, c1, 0, 0, 0);
+              acc[o0] = c0;
+              acc[o1] = c1;
+            }
           }
         }
       } else {
+        if (!DYN) {
+          v4f a0 = w0[0];
+          v4f c0 = acc[o0];
 #pragma unroll
-        for (int kt = 0; kt < KMAX; ++kt) {
-          if (!DYN || kt < K) acc[o0] = mfma4(w0[kt * 64], in[kt], acc[o0]);
+          for (int kt = 0; kt < KMAX; ++kt) {
+            v4f n0 = a0;
+            if (kt + 1 < KMAX) n0 = w0[(kt + 1) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+            c0 = mfma4(a0, in[kt], c0);
+            a0 = n0;
+          }
+          acc[o0] = c0;
+        } else {
+#pragma unroll
+          for (int kt = 0; kt < KMAX; ++kt) {
+            if (kt < K) acc[o0] = mfma4(w0[kt * 64], in[kt], acc[o0]);
+          }
         }
       }
 #if !MSDF_USE_GLDS

@@ -96,18 +96,27 @@ msdf_wgrad_k(const msdf_wgrad_item_t* __restrict__ items, const int* __restrict_
     if (wave_active) {
       const float* xa = xt + (lane >> 5) * it.wx + i_base + (lane & 31);
       const float* yb = yt + (lane >> 5) * it.wy + j_base + (lane & 31);
-#pragma unroll 4
+      // software-pipelined: the fragments of k-step k+1 are in flight while the 8 MFMAs of step k issue
+      float af[2][4], bf[2][2];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) af[0][a] = xa[32 * a];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) bf[0][b] = yb[32 * b];
+#pragma unroll
       for (int k = 0; k < WG_NP / 2; ++k) {
-        float af[4], bf[2];
+        const int cur = k & 1, nxt = cur ^ 1;
+        if (k + 1 < WG_NP / 2) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a) af[a] = xa[2 * k * it.wx + 32 * a];
+          for (int a = 0; a < 4; ++a) af[nxt][a] = xa[2 * (k + 1) * it.wx + 32 * a];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) bf[b] = yb[2 * k * it.wy + 32 * b];
+          for (int b = 0; b < 2; ++b) bf[nxt][b] = yb[2 * (k + 1) * it.wy + 32 * b];
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch above the MFMAs (the scheduler would sink it)
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
           for (int b = 0; b < 2; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][a], bf[cur][b], acc[a][b], 0, 0, 0);
       }
     }
     if (it.colsum_off >= 0 && tid < it.wx) {

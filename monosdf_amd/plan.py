@@ -324,18 +324,18 @@ def balanced_program(build, mp, P_pad, n_cu=256, max_stages=256):
     n_big = sum(1 for it in probe.items if it['weight'] == 1.0)
     n_half = sum(1 for it in probe.items if it['weight'] == 0.5)
     n_tiny = sum(1 for it in probe.items if it['weight'] == 0.0)
-    units = n_big + 0.5 * n_half
+    # column-sum-only items do no MFMA work but every stage still costs a memory round trip
+    # (~2 us against ~8 us for a full tile), so they get the split count of a half-weight item
+    units = n_big + 0.5 * (n_half + n_tiny)
     S = 1
     for k in range(1, 9):
-        S = int((k * n_cu - 2 * n_tiny) / max(units, 0.5))
+        S = int(k * n_cu / max(units, 0.5))
         if S >= 1 and (n_stages + S - 1) // S <= max_stages:
             break
     S = max(1, min(S, n_stages))
 
     def split_fn(w):
-        if w == 0.0:
-            return min(2, n_stages)
-        return max(1, min(n_stages, int(round(S * w))))
+        return max(1, min(n_stages, int(round(S * max(w, 0.5)))))
     return build(mp, P_pad, split_fn)
 
 

@@ -165,18 +165,20 @@ def test_hash_encoder_kernels():
                   geo['S'], geo['H'], 1, _lib.ptr(dy), st)
         assert rel_err(out, out_o) < 2e-6 and rel_err(dy, dy_o) < 2e-6
         grad = torch.randn(L, B, C, generator=g)
+        grad_g = grad.cuda()           # keep device tensors alive until the kernels have been enqueued
         ge_o = hg.encode_backward_grid(grad, x, geo, geo['n_entries'])
         gi_o = hg.encode_backward_input(grad, dy_o, geo)
         ge, gi = torch.zeros_like(eg), torch.zeros_like(xg)
-        _lib.call('msdf_hash_encode_backward', _lib.ptr(grad.cuda()), _lib.ptr(xg), _lib.ptr(eg), _lib.ptr(offs),
+        _lib.call('msdf_hash_encode_backward', _lib.ptr(grad_g), _lib.ptr(xg), _lib.ptr(eg), _lib.ptr(offs),
                   _lib.ptr(ge), B, 3, C, L, geo['S'], geo['H'], 1, _lib.ptr(dy), _lib.ptr(gi), st)
         assert rel_err(ge, ge_o) < 1e-5 and rel_err(gi, gi_o) < 1e-5
         ggi = torch.randn(B, 3, generator=g)
+        ggi_g = ggi.cuda()
         gg_o = hg.second_backward_grad(ggi, dy_o, geo)
         g2_o = hg.second_backward_embedding(grad, x, ggi, geo, geo['n_entries'])
         gg, g2 = torch.zeros(L, B, C, device='cuda'), torch.zeros_like(eg)
-        _lib.call('msdf_hash_encode_second_backward', _lib.ptr(grad.cuda()), _lib.ptr(xg), _lib.ptr(eg),
-                  _lib.ptr(offs), B, 3, C, L, geo['S'], geo['H'], 1, _lib.ptr(dy), _lib.ptr(ggi.cuda()),
+        _lib.call('msdf_hash_encode_second_backward', _lib.ptr(grad_g), _lib.ptr(xg), _lib.ptr(eg),
+                  _lib.ptr(offs), B, 3, C, L, geo['S'], geo['H'], 1, _lib.ptr(dy), _lib.ptr(ggi_g),
                   _lib.ptr(gg), _lib.ptr(g2), st)
         assert rel_err(gg, gg_o) < 1e-5 and rel_err(g2, g2_o) < 1e-5
 
