@@ -28,13 +28,16 @@ N_RAYS = 1024
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 
 
-def model_conf(width=256, depth=8):
+def model_conf(width=256, depth=8, grid=False):
     from monosdf_amd.conf import ConfigTree
     skip = [4] if depth > 4 else []
+    implicit = dict(d_in=3, d_out=1, dims=[width] * depth, geometric_init=True, bias=0.9, skip_in=skip,
+                    weight_norm=True, multires=6, inside_outside=True)
+    if grid:     # configs[2]: scannetGrids.conf:83-128 -- 16-level x 2-feature hash grid + 2x256 MLP
+        implicit.update(dims=[width, width], skip_in=[4], use_grid_feature=True, divide_factor=1.1)
     return ConfigTree.from_dict(dict(
-        feature_vector_size=width, scene_bounding_sphere=1.1, Grid_MLP=False,
-        implicit_network=dict(d_in=3, d_out=1, dims=[width] * depth, geometric_init=True, bias=0.9, skip_in=skip,
-                              weight_norm=True, multires=6, inside_outside=True),
+        feature_vector_size=width, scene_bounding_sphere=1.1, Grid_MLP=grid,
+        implicit_network=implicit,
         rendering_network=dict(mode='idr', d_in=9, d_out=3, dims=[width, width], weight_norm=True,
                                multires_view=4, per_image_code=False),
         density=dict(params_init=dict(beta=0.1), beta_min=0.0001),
@@ -88,12 +91,43 @@ def cpu_baseline(n_rays=256, iters=2):
                       % (n_rays, iters)}
 
 
+def grid_report(args, kern, dt, world, rounds, loss):
+    """configs[2]: roofline of the hash-grid entry points against HBM (SURVEY.md 8(d) bytes per point)."""
+    P_main, P_smp = N_RAYS * 98 + 4 * N_RAYS, N_RAYS * 128
+    # bytes per call of each entry point, summed over its launches in one step
+    per_step_bytes = {
+        'msdf_hash_encode_forward': 1164.0 * P_smp * rounds + 1548.0 * P_main,     # sampler (no dy_dx) + main (dy_dx)
+        'msdf_hash_encode_backward': 524.0 * P_main + 1164.0 * P_main,            # input-bwd (d/dx) + grid-bwd
+        'msdf_hash_encode_second_backward': (524.0 + 1176.0) * P_main,
+    }
+    rows = {}
+    for n, b in per_step_bytes.items():
+        if n in kern:
+            rows[n] = {'ms_per_step': kern[n]['ms_per_step'], 'algorithmic_GBps': b / (kern[n]['ms_per_step'] * 1e-3) / 1e9}
+    dom = max(rows, key=lambda n: rows[n]['ms_per_step'])
+    return {
+        'metric': 'rays/sec fwd+bwd, 1024 rays x 98 samples, 16x2 hash grid + 2x256 SDF MLP',
+        'value': world * N_RAYS * args.steps / dt, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'configs[2]: multi-res hash grid 16 levels x 2 feats (2^19 entries/level), '
+                               '1024 rays x 98 samples, training step', 'sampler_rounds': rounds},
+        'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': rows[dom]['algorithmic_GBps'], 'peak': 8000.0,
+                     'unit': 'GB/s', 'frac': rows[dom]['algorithmic_GBps'] / 8000.0, 'traffic': None},
+        'hash_entry_points': rows,
+        'kernels_ms_per_step': {k: round(v['ms_per_step'], 4) for k, v in sorted(kern.items())},
+        'loss': loss,
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--config', choices=['mlp', 'grid'], default='mlp',
+                    help="mlp = BASELINE.json configs[1] (the headline metric); grid = configs[2] (hash-grid path)")
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -109,7 +143,7 @@ def main():
     from monosdf_amd.model.network import MonoSDFNetwork
 
     torch.manual_seed(0)                      # same initial weights on every rank (as DDP would broadcast)
-    model = MonoSDFNetwork(model_conf()).to(device).train()
+    model = MonoSDFNetwork(model_conf(grid=(args.config == 'grid'))).to(device).train()
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.Adam(params, lr=5e-4)
     torch.manual_seed(1234 + rank)            # per-rank sampling noise
@@ -168,6 +202,11 @@ def main():
             'msdf_sdf_fwd_grad': 2.0 * 2 * F * (P_main + P_eik),   # forward + d/dx sweep
             'msdf_sdf_backward': 2.0 * 2 * F * (P_main + P_eik),   # p-bar = W q-bar and h-bar = W^T a-bar sweeps
         }
+        if args.config == 'grid':
+            print(json.dumps(grid_report(args, kern, dt, world, rounds, float(loss.item()))))
+            if world > 1:
+                dist.destroy_process_group()
+            return
         dom = max((n for n in kern if n in flops), key=lambda n: kern[n]['ms_per_step'])
         achieved = flops[dom] / (kern[dom]['avg_ms'] * 1e-3) / 1e12
         res = {

@@ -157,8 +157,11 @@ typedef struct {
   float* weights;            /* [N,S] */
   float* rgb_values;         /* [N,3] */
   float* depth_values;       /* [N] */
-  float* normal_map;         /* [N,3] */
+  float* normal_map;         /* [N,3]: R^T sum_i w_i n_i/(|n_i|+1e-6) (camera frame) when pose != NULL, else world frame */
   float* wsum;               /* [N] */
+  const float* pose;         /* [N or 1, 4, 4] camera-to-world matrices or NULL (reference network.py:608-616) */
+  int32_t pose_stride;       /* 16 per-ray poses, 0 one pose for all rays */
+  int32_t pad_;
 } msdf_composite_args_t;
 int msdf_composite_forward(const msdf_composite_args_t* args, void* stream);
 
@@ -183,6 +186,9 @@ typedef struct {
   float* g_rgb;               /* [N,S,3] */
   float* g_nrm;               /* [N,S,3] */
   float* g_beta_part;         /* [N] */
+  const float* pose;          /* as in the forward */
+  int32_t pose_stride;
+  int32_t pad_;
 } msdf_composite_bwd_args_t;
 int msdf_composite_backward(const msdf_composite_bwd_args_t* args, void* stream);
 

@@ -81,7 +81,7 @@ class CompositeArgs(C.Structure):
                 ('N', C.c_int32), ('S', C.c_int32), ('white_bkgd', C.c_int32),
                 ('bg0', C.c_float), ('bg1', C.c_float), ('bg2', C.c_float),
                 ('weights', _P), ('rgb_values', _P), ('depth_values', _P), ('normal_map', _P),
-                ('wsum', _P)]
+                ('wsum', _P), ('pose', _P), ('pose_stride', C.c_int32), ('pad_', C.c_int32)]
 
 
 class CompositeBwdArgs(C.Structure):
@@ -90,7 +90,8 @@ class CompositeBwdArgs(C.Structure):
                 ('g_depth', _P), ('g_normal', _P), ('g_weights', _P),
                 ('N', C.c_int32), ('S', C.c_int32), ('white_bkgd', C.c_int32),
                 ('bg0', C.c_float), ('bg1', C.c_float), ('bg2', C.c_float),
-                ('g_sdf', _P), ('g_rgb', _P), ('g_nrm', _P), ('g_beta_part', _P)]
+                ('g_sdf', _P), ('g_rgb', _P), ('g_nrm', _P), ('g_beta_part', _P),
+                ('pose', _P), ('pose_stride', C.c_int32), ('pad_', C.c_int32)]
 
 
 class SamplerArgs(C.Structure):

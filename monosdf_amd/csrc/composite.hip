@@ -93,6 +93,14 @@ msdf_composite_forward_k(const CompositeArgs a) {
     a.rgb_values[(size_t)ray * 3 + 1] = r1;
     a.rgb_values[(size_t)ray * 3 + 2] = r2;
     a.depth_values[ray] = a.depth_scale[ray] * (wz / (ws + 1e-8f));
+    if (a.pose != nullptr) {
+      // rotate into the camera frame: out = R^T m, R = pose[:3,:3]
+      const float* R = a.pose + (size_t)ray * a.pose_stride;
+      const float c0 = R[0] * m0 + R[4] * m1 + R[8] * m2;
+      const float c1 = R[1] * m0 + R[5] * m1 + R[9] * m2;
+      const float c2 = R[2] * m0 + R[6] * m1 + R[10] * m2;
+      m0 = c0; m1 = c1; m2 = c2;
+    }
     a.normal_map[(size_t)ray * 3 + 0] = m0;
     a.normal_map[(size_t)ray * 3 + 1] = m1;
     a.normal_map[(size_t)ray * 3 + 2] = m2;
@@ -140,6 +148,14 @@ msdf_composite_backward_k(const CompositeBwdArgs a) {
     gM0 = a.g_normal[(size_t)ray * 3 + 0];
     gM1 = a.g_normal[(size_t)ray * 3 + 1];
     gM2 = a.g_normal[(size_t)ray * 3 + 2];
+    if (a.pose != nullptr) {
+      // adjoint of out = R^T m:  g_m = R g_out
+      const float* R = a.pose + (size_t)ray * a.pose_stride;
+      const float w0 = R[0] * gM0 + R[1] * gM1 + R[2] * gM2;
+      const float w1 = R[4] * gM0 + R[5] * gM1 + R[6] * gM2;
+      const float w2 = R[8] * gM0 + R[9] * gM1 + R[10] * gM2;
+      gM0 = w0; gM1 = w1; gM2 = w2;
+    }
   }
   // depth = ds * wz / (ws + eps):  d/dw_i = ds * (z_i - wz/(ws+eps)) / (ws + eps)
   const float inv = 1.0f / (ws + 1e-8f);

@@ -205,6 +205,25 @@ __device__ __forceinline__ void gemm_dispatch(const int kp, v4f (&acc)[MT], cons
   }
 }
 
+// Pull the 16-point x (16*tiles)-float rows this wave will read after the next GEMM towards L2:
+// one dword per 128-byte line.  The values are kept in a tiny struct that the caller retires with
+// touch_retire() AFTER the GEMM, so the compiler's own s_waitcnt lands there (latency hidden by the GEMM).
+struct Touch { float v[3]; };
+__device__ __forceinline__ Touch touch_rows(const float* __restrict__ row0, const int tiles) {
+  const int bytes = 16 * 16 * 4 * tiles;     // 16 points x 64 B per tile
+  const char* base = (const char*)row0;
+  Touch t;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int off = (lane_id() + 64 * i) * 128;
+    t.v[i] = (off < bytes) ? *(const float*)(base + off) : 0.f;
+  }
+  return t;
+}
+__device__ __forceinline__ void touch_retire(const Touch& t) {
+  asm volatile("" ::"v"(t.v[0]), "v"(t.v[1]), "v"(t.v[2]));
+}
+
 __device__ __forceinline__ void zero_tiles(v4f (&a)[MT]) {
 #pragma unroll
   for (int t = 0; t < MT; ++t) a[t] = V4ZERO;

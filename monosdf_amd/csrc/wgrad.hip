@@ -46,8 +46,12 @@ msdf_wgrad_k(const msdf_wgrad_item_t* __restrict__ items, const int* __restrict_
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wi = wave >> 2, wj = wave & 3;     // 2 x 4 waves: 128 rows x 64 cols each
-  const int i_base = 128 * wi, j_base = 64 * wj;
+  // wide items: 2 x 4 waves, 128 rows x 64 cols each (4 x 2 MFMA tiles per wave);
+  // narrow items (wy <= 64): 8 x 1 waves, 32 rows x 64 cols each, so all 8 waves (all 4 SIMDs) work
+  const bool narrow = it.wy <= 64;
+  const int wi = narrow ? wave : (wave >> 2), wj = narrow ? 0 : (wave & 3);
+  const int i_base = narrow ? 32 * wi : 128 * wi, j_base = 64 * wj;
+  const int na = narrow ? 1 : 4;
 
   // point range of this split, in stages of WG_NP points
   const int n_stages_total = P_pad / WG_NP;
@@ -72,7 +76,7 @@ msdf_wgrad_k(const msdf_wgrad_item_t* __restrict__ items, const int* __restrict_
   // which of this wave's tiles are inside [wx x wy]
   bool ai[4], bj[2];
 #pragma unroll
-  for (int a = 0; a < 4; ++a) ai[a] = (i_base + 32 * a) < it.wx;
+  for (int a = 0; a < 4; ++a) ai[a] = (a < na) && (i_base + 32 * a) < it.wx;
 #pragma unroll
   for (int b = 0; b < 2; ++b) bj[b] = (j_base + 32 * b) < it.wy;
   const bool wave_active = do_mm && ai[0] && bj[0];
@@ -85,11 +89,17 @@ msdf_wgrad_k(const msdf_wgrad_item_t* __restrict__ items, const int* __restrict_
     if (V != nullptr && tid < WG_NP) base[2 * WG_TILE_F + tid] = V[p0 + tid];
   };
 
-  if (s_begin < s_end) issue(s_begin, 0);
+  // Every workgroup walks its stages from a different starting phase (and wraps around): the streams of
+  // the ~250 workgroups are laid out at equal strides, and walking them in lockstep would keep them all
+  // on the same HBM channels.  The summation order inside a workgroup stays fixed (deterministic).
+  const int n_st = max(0, s_end - s_begin);
+  const int rot = (n_st > 0) ? (int)((blockIdx.x * 0x9E3779B1u) >> 8) % n_st : 0;
+  auto stage_of = [&](int j) { int t = j + rot; if (t >= n_st) t -= n_st; return s_begin + t; };
+  if (n_st > 0) issue(stage_of(0), 0);
   __syncthreads();
-  for (int s = s_begin; s < s_end; ++s) {
-    const int buf = (s - s_begin) & 1;
-    if (s + 1 < s_end) issue(s + 1, buf ^ 1);
+  for (int j = 0; j < n_st; ++j) {
+    const int buf = j & 1;
+    if (j + 1 < n_st) issue(stage_of(j + 1), buf ^ 1);
     const float* xt = lds_f + buf * WG_STAGE_F;
     const float* yt = xt + WG_TILE_F;
     const float* vt = xt + 2 * WG_TILE_F;
@@ -112,11 +122,17 @@ msdf_wgrad_k(const msdf_wgrad_item_t* __restrict__ items, const int* __restrict_
           for (int b = 0; b < 2; ++b) bf[nxt][b] = yb[2 * (k + 1) * it.wy + 32 * b];
         }
         __builtin_amdgcn_sched_barrier(0);   // keep the prefetch above the MFMAs (the scheduler would sink it)
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
+        if (narrow) {
 #pragma unroll
           for (int b = 0; b < 2; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][a], bf[cur][b], acc[a][b], 0, 0, 0);
+            acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][0], bf[cur][b], acc[0][b], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][a], bf[cur][b], acc[a][b], 0, 0, 0);
+        }
       }
     }
     if (it.colsum_off >= 0 && tid < it.wx) {

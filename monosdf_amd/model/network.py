@@ -315,6 +315,13 @@ class MonoSDFNetwork(nn.Module):
         self.ray_sampler = ErrorBoundSampler(self.scene_bounding_sphere, **conf.get_config('ray_sampler'))
         self._noise = None      # tests inject the six random draws here (SURVEY.md 8(a) RNG note)
 
+    def _bg_list(self):
+        bg = getattr(self, '_bg_cache', None)
+        if bg is None:
+            bg = [float(v) for v in self.bg_color.tolist()]
+            object.__setattr__(self, '_bg_cache', bg)
+        return bg
+
     # -- rays ------------------------------------------------------------------------------
     def _rays(self, input_dict, if_pixel_input):
         if not if_pixel_input:
@@ -366,9 +373,11 @@ class MonoSDFNetwork(nn.Module):
             rgb_flat = self.rendering_network(points_flat, gradients_sdf, ray_dirs, feature_vectors, indices,
                                               if_pixel_input=if_pixel_input, samples_per_ray=S)['rgb']
             rgb = rgb_flat.reshape(-1, S, 3)
+            # the compositor also rotates the normal map into the camera frame (R^T, reference 608-616)
+            pose = input_dict['ray_pose'] if if_pixel_input else input_dict['pose'][:1]
             weights, rgb_values, depth_values, normal_map = ops.CompositeFunction.apply(
                 z_vals, sdf, rgb_flat, gradients_sdf, self.density.get_beta(), depth_scale, self.white_bkgd,
-                [float(v) for v in self.bg_color.tolist()])
+                self._bg_list(), pose)
         finally:
             net.unshare()
             self.rendering_network.unshare()
@@ -386,13 +395,6 @@ class MonoSDFNetwork(nn.Module):
             grad_theta = grad_all[P:]
             output['grad_theta'] = grad_theta[:grad_theta.shape[0] // 2]
             output['grad_theta_nei'] = grad_theta[grad_theta.shape[0] // 2:]
-        # the compositor returns sum_i w_i n_i / (|n_i| + 1e-6) in world coordinates; rotate into the camera
-        if if_pixel_input:
-            rot = input_dict['ray_pose'][:, :3, :3].transpose(1, 2)
-            normal_map = (rot @ normal_map.unsqueeze(-1)).squeeze(-1)
-        else:
-            rot = input_dict['pose'][0, :3, :3].permute(1, 0).contiguous()
-            normal_map = (rot @ normal_map.permute(1, 0)).permute(1, 0).contiguous()
         output['normal_map'] = normal_map
         return output
 

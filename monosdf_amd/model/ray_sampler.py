@@ -31,6 +31,8 @@ class ErrorBoundSampler(RaySampler):
         self.scene_bounding_sphere = scene_bounding_sphere
         self.add_tiny = add_tiny
         self.last_rounds = 0
+        # Lemma-2 constant, formed in fp32 like the reference does (ray_sampler.py:119)
+        self._lemma = float(1.0 / (4.0 * torch.log(torch.tensor(self.eps + 1.0))))
 
     def get_z_vals(self, ray_dirs, cam_loc, model):
         dev = ray_dirs.device
@@ -61,7 +63,7 @@ class ErrorBoundSampler(RaySampler):
             jitter = torch.rand(N, n_eval, **f32) if jitter is None else jitter.to(**f32).contiguous()
             u_final = noise.get('final_u')
             u_final = torch.rand(N, n_final, **f32) if u_final is None else u_final.to(**f32).contiguous()
-        lemma = float(1.0 / (4.0 * torch.log(torch.tensor(self.eps + 1.0))))
+        lemma = self._lemma
         a = _lib.SamplerArgs()
         a.ray_o, a.ray_d, a.N = cam_loc.data_ptr(), ray_dirs.data_ptr(), N
         a.m_max, a.n_eval, a.n_final, a.n_extra = m_max, n_eval, n_final, n_extra
@@ -95,13 +97,15 @@ class ErrorBoundSampler(RaySampler):
         if n_extra > 0:
             extra_idx = noise.get('extra_idx') if training else None
             if extra_idx is None:
-                extra_idx = torch.randperm(M)[:n_extra] if training else torch.linspace(0, M - 1, n_extra).long()
+                # drawn on the device (the reference draws on the CPU generator; same distribution, no H2D copy)
+                extra_idx = (torch.randperm(M, device=dev)[:n_extra] if training
+                             else torch.linspace(0, M - 1, n_extra, device=dev).long())
             extra_idx = extra_idx.to(device=dev, dtype=torch.int64).contiguous()
         else:
             extra_idx = torch.zeros(1, device=dev, dtype=torch.int64)
         eik_idx = noise.get('eik_idx')
         if eik_idx is None:
-            eik_idx = torch.randint(S, (N,))
+            eik_idx = torch.randint(S, (N,), device=dev)
         eik_idx = eik_idx.to(device=dev, dtype=torch.int64).contiguous()
         z_out = torch.empty(N, S, **f32)
         z_eik = torch.empty(N, 1, **f32)

@@ -264,7 +264,7 @@ class CompositeFunction(torch.autograd.Function):
     """(z, sdf, rgb, normals, beta, depth_scale) -> weights, rgb_values, depth_values, normal_map."""
 
     @staticmethod
-    def forward(ctx, z, sdf, rgb, nrm, beta, depth_scale, white_bkgd, bg):
+    def forward(ctx, z, sdf, rgb, nrm, beta, depth_scale, white_bkgd, bg, pose=None):
         z = _need_cuda(z.detach(), 'z_vals')
         N, S = z.shape
         ctx.in_shapes = (sdf.shape, rgb.shape, nrm.shape)
@@ -286,15 +286,24 @@ class CompositeFunction(torch.autograd.Function):
         a.bg0, a.bg1, a.bg2 = [float(v) for v in bg]
         a.weights, a.rgb_values, a.depth_values = weights.data_ptr(), rgb_values.data_ptr(), depth_values.data_ptr()
         a.normal_map, a.wsum = normal_map.data_ptr(), wsum.data_ptr()
+        if pose is not None:
+            pose = _need_cuda(pose.detach(), 'pose').reshape(-1, 4, 4)
+            if pose.shape[0] not in (1, N):
+                raise RuntimeError('monosdf_amd: pose must be [1,4,4] or [N,4,4]')
+            a.pose, a.pose_stride = pose.data_ptr(), (16 if pose.shape[0] == N and N > 1 else 0)
+        else:
+            pose = z.new_zeros(1)
+            a.pose, a.pose_stride = None, 0
+        ctx.has_pose, ctx.pose_stride = a.pose is not None, a.pose_stride
         _lib.call('msdf_composite_forward', C.byref(a), _lib.stream_ptr())
-        ctx.save_for_backward(z, sdf, rgb, nrm, beta, depth_scale, weights, wsum, depth_values)
+        ctx.save_for_backward(z, sdf, rgb, nrm, beta, depth_scale, weights, wsum, depth_values, pose)
         ctx.white_bkgd, ctx.bg = white_bkgd, [float(v) for v in bg]
         return weights, rgb_values, depth_values, normal_map
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_w, g_rgbv, g_depth, g_nmap):
-        z, sdf, rgb, nrm, beta, depth_scale, weights, wsum, depth_values = ctx.saved_tensors
+        z, sdf, rgb, nrm, beta, depth_scale, weights, wsum, depth_values, pose = ctx.saved_tensors
         N, S = z.shape
         dev = z.device
         cont = lambda t: None if t is None else t.contiguous()
@@ -315,10 +324,11 @@ class CompositeFunction(torch.autograd.Function):
         b.bg0, b.bg1, b.bg2 = ctx.bg
         b.g_sdf, b.g_rgb, b.g_nrm, b.g_beta_part = g_sdf.data_ptr(), g_rgb.data_ptr(), g_nrm.data_ptr(), \
             g_beta_part.data_ptr()
+        b.pose, b.pose_stride = (pose.data_ptr() if ctx.has_pose else None), ctx.pose_stride
         _lib.call('msdf_composite_backward', C.byref(b), _lib.stream_ptr())
         g_beta = g_beta_part[:N].sum().reshape(beta.shape)
         sh = ctx.in_shapes
-        return (None, g_sdf.reshape(sh[0]), g_rgb.reshape(sh[1]), g_nrm.reshape(sh[2]), g_beta, None, None, None)
+        return (None, g_sdf.reshape(sh[0]), g_rgb.reshape(sh[1]), g_nrm.reshape(sh[2]), g_beta, None, None, None, None)
 
 
 # ---------------------------------------------------------------------------

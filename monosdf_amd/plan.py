@@ -271,6 +271,8 @@ class WgradProgram:
         8 waves have a tile, 0 for column-sum-only items."""
         if wy == 0:
             return 0.0
+        if wy <= 64:
+            return 0.3          # narrow mode: 2 MFMAs per k-step and wave instead of 8, then memory latency
         active = min(2, (wx + 127) // 128) * min(4, (wy + 63) // 64)
         return 1.0 if active > 4 else 0.5
 
@@ -322,20 +324,18 @@ def balanced_program(build, mp, P_pad, n_cu=256, max_stages=256):
     n_stages = max(1, P_pad // 32)
     probe = build(mp, P_pad, lambda w: 1)
     n_big = sum(1 for it in probe.items if it['weight'] == 1.0)
-    n_half = sum(1 for it in probe.items if it['weight'] == 0.5)
-    n_tiny = sum(1 for it in probe.items if it['weight'] == 0.0)
-    # column-sum-only items do no MFMA work but every stage still costs a memory round trip
-    # (~2 us against ~8 us for a full tile), so they get the split count of a half-weight item
-    units = n_big + 0.5 * (n_half + n_tiny)
+    # a stage of a narrow / column-sum-only item costs about a memory round trip (~2.5 us against ~8 us for a
+    # full 256x256 tile), hence the 0.3 floor on the duration weight
+    units = sum(max(it['weight'], 0.3) for it in probe.items)
     S = 1
     for k in range(1, 9):
-        S = int(k * n_cu / max(units, 0.5))
+        S = int(k * n_cu / max(units, 0.3))
         if S >= 1 and (n_stages + S - 1) // S <= max_stages:
             break
     S = max(1, min(S, n_stages))
 
     def split_fn(w):
-        return max(1, min(n_stages, int(round(S * max(w, 0.5)))))
+        return max(1, min(n_stages, int(round(S * max(w, 0.3)))))
     return build(mp, P_pad, split_fn)
 
 
