@@ -124,29 +124,31 @@ hg_forward_kernel(const float* __restrict__ inputs, const float* __restrict__ gr
 }
 
 // ---------------------------------------------------------------------------
-// grid backward: scatter w * grad into the 8 corners (float atomics, like the reference)
+// grid backward: scatter w * grad into the 8 corners (float atomics, like the reference).
+// Lane mapping: C consecutive lanes own the C channels of ONE (point, level), so a wave-instruction
+// adds 64/C entries of C contiguous floats each -- half (C=2) as many distinct memory segments per
+// instruction as one-point-per-lane, which is what the memory-side atomic units are paced by
+// (MI355X_MICROARCH.md "Global float atomics", access-shape row).
 // ---------------------------------------------------------------------------
 template <int C>
 __global__ void __launch_bounds__(HG_THREADS)
 hg_backward_grid_kernel(const float* __restrict__ grad, const float* __restrict__ inputs,
                         const int* __restrict__ offsets, float* __restrict__ grad_grid, const uint32_t B,
                         const uint32_t L, const float S, const uint32_t H) {
-  const uint32_t b = blockIdx.x * HG_THREADS + threadIdx.x;
+  const uint32_t t = blockIdx.x * HG_THREADS + threadIdx.x;
+  const uint32_t b = t / C, ch = t % C;
   if (b >= B) return;
   const uint32_t level = blockIdx.y;
   const HgCell c = hg_locate(inputs, offsets, b, level, S, H);
   if (c.oob) return;
-  float g[C];
-#pragma unroll
-  for (int ch = 0; ch < C; ++ch) g[ch] = grad[((size_t)level * B + b) * C + ch];
-  float* table = grad_grid + (size_t)(uint32_t)offsets[level] * C;
+  const float g = grad[((size_t)level * B + b) * C + ch];
+  float* table = grad_grid + (size_t)(uint32_t)offsets[level] * C + ch;
   const float wx[2] = {1.f - c.sx, c.sx}, wy[2] = {1.f - c.sy, c.sy}, wz[2] = {1.f - c.sz, c.sz};
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const float w = wx[k & 1] * wy[(k >> 1) & 1] * wz[(k >> 2) & 1];
     const uint32_t idx = hg_index(c.gx + (k & 1), c.gy + ((k >> 1) & 1), c.gz + ((k >> 2) & 1), c.hsize, c.res);
-#pragma unroll
-    for (int ch = 0; ch < C; ++ch) unsafeAtomicAdd(table + (size_t)idx * C + ch, w * g[ch]);
+    unsafeAtomicAdd(table + (size_t)idx * C, w * g);
   }
 }
 
@@ -189,25 +191,25 @@ hg_second_backward_grad_kernel(const float* __restrict__ gg_inputs, const float*
 }
 
 // d/d embeddings of (gg_inputs . d enc/dx): +-(w * grad * gg[d] * smoothstep'(d) * scale) on the corner pairs
+// (same channel-per-lane mapping as the grid backward)
 template <int C>
 __global__ void __launch_bounds__(HG_THREADS)
 hg_second_backward_embedding_kernel(const float* __restrict__ grad, const float* __restrict__ inputs,
                                     const int* __restrict__ offsets, const float* __restrict__ gg_inputs,
                                     float* __restrict__ grad2_grid, const uint32_t B, const uint32_t L,
                                     const float S, const uint32_t H) {
-  const uint32_t b = blockIdx.x * HG_THREADS + threadIdx.x;
+  const uint32_t t = blockIdx.x * HG_THREADS + threadIdx.x;
+  const uint32_t b = t / C, ch = t % C;
   if (b >= B) return;
   const uint32_t level = blockIdx.y;
   const HgCell c = hg_locate(inputs, offsets, b, level, S, H);
   if (c.oob) return;
-  float g[C];
-#pragma unroll
-  for (int ch = 0; ch < C; ++ch) g[ch] = grad[((size_t)level * B + b) * C + ch];
+  const float g = grad[((size_t)level * B + b) * C + ch];
   const float q0 = gg_inputs[(size_t)b * 3 + 0] * c.dx * c.scale;
   const float q1 = gg_inputs[(size_t)b * 3 + 1] * c.dy * c.scale;
   const float q2 = gg_inputs[(size_t)b * 3 + 2] * c.dz * c.scale;
   const float wx[2] = {1.f - c.sx, c.sx}, wy[2] = {1.f - c.sy, c.sy}, wz[2] = {1.f - c.sz, c.sz};
-  float* table = grad2_grid + (size_t)(uint32_t)offsets[level] * C;
+  float* table = grad2_grid + (size_t)(uint32_t)offsets[level] * C + ch;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int bx = k & 1, by = (k >> 1) & 1, bz = (k >> 2) & 1;
@@ -215,8 +217,7 @@ hg_second_backward_embedding_kernel(const float* __restrict__ grad, const float*
     const float coef = (bx ? 1.f : -1.f) * wy[by] * wz[bz] * q0 + (by ? 1.f : -1.f) * wx[bx] * wz[bz] * q1 +
                        (bz ? 1.f : -1.f) * wx[bx] * wy[by] * q2;
     const uint32_t idx = hg_index(c.gx + bx, c.gy + by, c.gz + bz, c.hsize, c.res);
-#pragma unroll
-    for (int ch = 0; ch < C; ++ch) unsafeAtomicAdd(table + (size_t)idx * C + ch, coef * g[ch]);
+    unsafeAtomicAdd(table + (size_t)idx * C, coef * g);
   }
 }
 
@@ -255,8 +256,9 @@ extern "C" int msdf_hash_encode_backward(const float* grad, const float* inputs,
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((B + HG_THREADS - 1) / HG_THREADS, L);
   HG_DISPATCH_C(C, {
+    const dim3 grid_c((B * CC + HG_THREADS - 1) / HG_THREADS, L);   // one lane per (point, channel)
     if (grad_embeddings != nullptr)
-      hg_backward_grid_kernel<CC><<<grid, HG_THREADS, 0, st>>>(grad, inputs, offsets, grad_embeddings, B, L, S, H);
+      hg_backward_grid_kernel<CC><<<grid_c, HG_THREADS, 0, st>>>(grad, inputs, offsets, grad_embeddings, B, L, S, H);
     if (calc_grad_inputs)
       hg_backward_input_kernel<CC><<<grid.x, HG_THREADS, 0, st>>>(grad, dy_dx, grad_inputs, B, L);
   });
@@ -276,8 +278,9 @@ extern "C" int msdf_hash_encode_second_backward(const float* grad, const float* 
   const dim3 grid((B + HG_THREADS - 1) / HG_THREADS, L);
   HG_DISPATCH_C(C, {
     hg_second_backward_grad_kernel<CC><<<grid, HG_THREADS, 0, st>>>(grad_grad_inputs, dy_dx, grad_grad, B, L);
-    hg_second_backward_embedding_kernel<CC><<<grid, HG_THREADS, 0, st>>>(grad, inputs, offsets, grad_grad_inputs,
-                                                                         grad2_embeddings, B, L, S, H);
+    const dim3 grid_c((B * CC + HG_THREADS - 1) / HG_THREADS, L);
+    hg_second_backward_embedding_kernel<CC><<<grid_c, HG_THREADS, 0, st>>>(grad, inputs, offsets, grad_grad_inputs,
+                                                                           grad2_embeddings, B, L, S, H);
   });
   return msdf_check_launch();
 }

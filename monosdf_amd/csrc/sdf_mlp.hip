@@ -281,15 +281,8 @@ msdf_sdf_fwd_grad_k(const msdf_plan_t plan, const FgArgs a) {
       }
       in[t] = p;
     }
-    Touch th;
-    th.v[0] = th.v[1] = th.v[2] = 0.f;
-    if (l > 0) {
-      const msdf_layer_t Ln = plan.layer[l - 1];
-      th = touch_rows(a.H + (size_t)Ln.hpre * Pp + (size_t)(c.pt - (lane_id() & 15)) * (16 * Ln.ot), Ln.ot);
-    }
     zero_tiles(acc);
     gemm_dispatch(L.otp, acc, in, L.kt, (const v4f*)a.wpack + L.wb_off, lds);
-    touch_retire(th);
     if (l == 0) {
       gather_tiles(r_in, acc, 0, in0_tiles);
     } else if (L.skip_tile >= 0) {
@@ -393,12 +386,8 @@ msdf_sdf_backward_k(const msdf_plan_t plan, const BwArgs a) {
 #pragma unroll
     for (int t = 0; t < MT; ++t)
       if (t < L.kt) *(v4f*)(Ql + 16 * t) = in[t];
-    const size_t row0 = (size_t)L.hpre * Pp + (size_t)(c.pt - (lane_id() & 15)) * (16 * L.ot);
-    const Touch th = touch_rows(a.H + row0, L.ot), tp = touch_rows(a.PM + row0, L.ot);
     zero_tiles(acc);
     gemm_dispatch(L.ktp, acc, in, L.ot, (const v4f*)a.wpack + L.wf_off, lds);
-    touch_retire(th);
-    touch_retire(tp);
     const size_t off = (size_t)L.hpre * Pp + (size_t)c.pt * (16 * L.ot) + 4 * c.q;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
@@ -445,15 +434,8 @@ msdf_sdf_backward_k(const msdf_plan_t plan, const BwArgs a) {
       in[t] = v;
     }
   }
-  {
-    const msdf_layer_t Ln = plan.layer[nl - 2];
-    const size_t row0 = (size_t)Ln.hpre * Pp + (size_t)(c.pt - (lane_id() & 15)) * (16 * Ln.ot);
-    const Touch th = touch_rows(a.H + row0, Ln.ot), tt = touch_rows(a.T + row0, Ln.ot);
-    zero_tiles(acc);
-    gemm_dispatch(LL.otp, acc, in, LL.kt, (const v4f*)a.wpack + LL.wb_off, lds);
-    touch_retire(th);
-    touch_retire(tt);
-  }
+  zero_tiles(acc);
+  gemm_dispatch(LL.otp, acc, in, LL.kt, (const v4f*)a.wpack + LL.wb_off, lds);
   v4f gin0[5];
 #pragma unroll
   for (int t = 0; t < 5; ++t) gin0[t] = V4ZERO;
@@ -474,18 +456,8 @@ msdf_sdf_backward_k(const msdf_plan_t plan, const BwArgs a) {
       in[t] = ab;
     }
     if (l == 0 && a.g_aux == nullptr) break;   // d loss / d x is not needed: skip the last product
-    Touch th2, tt2;
-    th2.v[0] = th2.v[1] = th2.v[2] = tt2.v[0] = tt2.v[1] = tt2.v[2] = 0.f;
-    if (l > 0) {
-      const msdf_layer_t Ln = plan.layer[l - 1];
-      const size_t row0 = (size_t)Ln.hpre * Pp + (size_t)(c.pt - (lane_id() & 15)) * (16 * Ln.ot);
-      th2 = touch_rows(a.H + row0, Ln.ot);
-      tt2 = touch_rows(a.T + row0, Ln.ot);
-    }
     zero_tiles(acc);
     gemm_dispatch(L.otp, acc, in, L.kt, (const v4f*)a.wpack + L.wb_off, lds);
-    touch_retire(th2);
-    touch_retire(tt2);
     if (a.g_aux != nullptr) {
       if (l == 0) gather_tiles(gin0, acc, 0, in0_tiles);
       else if (L.skip_tile >= 0) gather_tiles(gin0, acc, L.skip_tile, in0_tiles);

@@ -318,25 +318,16 @@ class WgradProgram:
         return np.frombuffer(b''.join(out), dtype=np.uint8).copy()
 
 
-def balanced_program(build, mp, P_pad, n_cu=256, max_stages=256):
-    """Run `build` twice: once to count the items per duration class, once with split counts that make
-    (#workgroups) ~ k * n_cu with equally long workgroups (k as small as the stage cap allows)."""
-    n_stages = max(1, P_pad // 32)
-    probe = build(mp, P_pad, lambda w: 1)
-    n_big = sum(1 for it in probe.items if it['weight'] == 1.0)
-    # a stage of a narrow / column-sum-only item costs about a memory round trip (~2.5 us against ~8 us for a
-    # full 256x256 tile), hence the 0.3 floor on the duration weight
-    units = sum(max(it['weight'], 0.3) for it in probe.items)
-    S = 1
-    for k in range(1, 9):
-        S = int(k * n_cu / max(units, 0.3))
-        if S >= 1 and (n_stages + S - 1) // S <= max_stages:
-            break
-    S = max(1, min(S, n_stages))
+def balanced_program(build, mp, P_pad, target_stages=51):
+    """Split every item's point range into workgroups of about `target_stages` 32-point stages.
 
-    def split_fn(w):
-        return max(1, min(n_stages, int(round(S * max(w, 0.3)))))
-    return build(mp, P_pad, split_fn)
+    Measured on MI355X (scripts/bench_wgrad.py, profiles/README.md): many short workgroups (~50 stages,
+    5 rounds over the 256 CUs) beat one long workgroup per CU by 25 % -- long lock-stepped workgroups run
+    their stages ~40 % slower -- and giving the narrow / column-sum-only items the same split count keeps
+    their latency-bound stages off the critical path."""
+    n_stages = max(1, P_pad // 32)
+    S = max(1, (n_stages + target_stages - 1) // target_stages)
+    return build(mp, P_pad, lambda w: S)
 
 
 def _col_parts(L, in0_tiles):

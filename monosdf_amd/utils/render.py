@@ -1,0 +1,138 @@
+"""Full-image inference and SDF-volume evaluation on top of the fused kernels.
+
+* ``render_image``: the chunked image loop of the reference (utils/general.py:28-58 split_input /
+  merge_output; evaluation/eval.py:105-120; training/monosdf_train.py:351-370), chunks sharded over
+  ranks (chunk c -> rank c mod world) and the rendered rows all-gathered over RCCL.
+* ``sdf_volume``: the SDF-evaluation part of plots.get_surface_sliding (utils/plots.py:108-190): a
+  4-level coarse-to-fine pyramid per block, only voxels with |sdf| < threshold refined; every level is
+  one call of the no-grad forward kernel on the GPU (the reference moves 100k-point chunks to the CPU).
+  Marching cubes itself (skimage, plots.py:199) stays with the caller.
+"""
+import numpy as np
+import torch
+
+from .. import parallel
+
+
+def split_input(model_input, total_pixels, n_pixels=10000):
+    """Slices of ``uv`` (and masks / depth when present) of at most n_pixels (general.py:28-42)."""
+    chunks = []
+    for idx in torch.split(torch.arange(total_pixels, device=model_input['uv'].device), n_pixels, dim=0):
+        data = dict(model_input)
+        data['uv'] = torch.index_select(model_input['uv'], 1, idx)
+        for k in ('object_mask', 'depth'):
+            if k in data:
+                data[k] = torch.index_select(model_input[k], 1, idx)
+        chunks.append(data)
+    return chunks
+
+
+def merge_output(res, total_pixels, batch_size):
+    """Concatenate per-chunk outputs (general.py:44-58)."""
+    out = {}
+    for k in res[0]:
+        if res[0][k] is None:
+            continue
+        if res[0][k].dim() == 1:
+            out[k] = torch.cat([r[k].reshape(batch_size, -1, 1) for r in res], 1).reshape(batch_size * total_pixels)
+        else:
+            out[k] = torch.cat([r[k].reshape(batch_size, -1, r[k].shape[-1]) for r in res],
+                               1).reshape(batch_size * total_pixels, -1)
+    return out
+
+
+_WIDTH = {'rgb_values': 3, 'normal_map': 3, 'depth_values': 1}
+
+
+@torch.no_grad()
+def render_image(model, model_input, indices, total_pixels, split_n_pixels=1024,
+                 keys=('rgb_values', 'normal_map', 'depth_values')):
+    """Eval-mode render of all pixels of ``model_input['uv']``; returns {key: [total_pixels, C]} on every rank.
+    Chunk c is rendered by rank c mod world; one ragged all-gather reassembles the image."""
+    was_training = model.training
+    model.eval()
+    try:
+        chunks = split_input(model_input, total_pixels, split_n_pixels)
+        world, rank = parallel.world(), parallel.rank()
+        rows = []
+        for c in range(rank, len(chunks), world):
+            out = model(chunks[c], indices)
+            rows.append(torch.cat([out[k].reshape(out[k].shape[0], -1) for k in keys], 1))
+        width = sum(_WIDTH[k] for k in keys)
+        local = torch.cat(rows, 0) if rows else torch.zeros(0, width, device=model_input['uv'].device)
+        if world > 1:
+            gathered = parallel.all_gather_rows(local)
+            n_chunk = [ch['uv'].shape[1] for ch in chunks]
+            span, off = {}, 0
+            for r in range(world):                       # rank-major order of the gathered rows
+                for c in range(r, len(chunks), world):
+                    span[c] = (off, off + n_chunk[c])
+                    off += n_chunk[c]
+            full = torch.cat([gathered[span[c][0]:span[c][1]] for c in range(len(chunks))], 0)
+        else:
+            full = local
+        result, col = {}, 0
+        for k in keys:
+            result[k] = full[:, col:col + _WIDTH[k]]
+            col += _WIDTH[k]
+        return result
+    finally:
+        model.train(was_training)
+
+
+def _pyramid(points, levels=3):
+    """[3, n, n, n] -> list coarse..fine by 2x average pooling (plots.py:154-159)."""
+    pyr = [points]
+    pool = torch.nn.AvgPool3d(2, stride=2)
+    for _ in range(levels):
+        points = pool(points[None])[0]
+        pyr.append(points)
+    return pyr[::-1]
+
+
+@torch.no_grad()
+def sdf_volume(sdf_fn, resolution=512, grid_boundary=(-1.1, 1.1), device='cuda', shard=True):
+    """Yields (origin[3], spacing[3], volume[cropN, cropN, cropN] float32 numpy) per block of the sliding
+    window, exactly the array the reference hands to marching cubes.  ``sdf_fn(points[P,3]) -> [P]``."""
+    cropN = 128 if resolution < 512 else 512
+    assert resolution % cropN == 0
+    N = resolution // cropN
+    lo, hi = grid_boundary
+    edges = np.linspace(lo, hi, N + 1)
+    upsample = torch.nn.Upsample(scale_factor=2, mode='nearest')
+    world, rank = (parallel.world(), parallel.rank()) if shard else (1, 0)
+
+    def evaluate(pts):
+        if world == 1:
+            return sdf_fn(pts).reshape(-1)
+        a, b = parallel.shard_slice(pts.shape[0], rank, world)
+        part = sdf_fn(pts[a:b].contiguous()).reshape(-1, 1) if b > a else pts.new_zeros(0, 1)
+        return parallel.all_gather_rows(part).reshape(-1)
+
+    for i in range(N):
+        for j in range(N):
+            for k in range(N):
+                mins = (edges[i], edges[j], edges[k])
+                maxs = (edges[i + 1], edges[j + 1], edges[k + 1])
+                axes = [torch.tensor(np.linspace(mins[d], maxs[d], cropN)) for d in range(3)]
+                xx, yy, zz = torch.meshgrid(*axes, indexing='ij')
+                pts = torch.vstack([xx.flatten(), yy.flatten(), zz.flatten()]).T.float().to(device)
+                pyr = _pyramid(pts.reshape(cropN, cropN, cropN, 3).permute(3, 0, 1, 2))
+                mask, vals = None, None
+                threshold = 2 * (maxs[0] - mins[0]) / cropN * 8
+                for pid, p in enumerate(pyr):
+                    n = p.shape[-1]
+                    flat = p.reshape(3, -1).permute(1, 0).contiguous()
+                    if mask is None:
+                        vals = evaluate(flat)
+                    else:
+                        m = mask.reshape(-1)
+                        if bool(m.any()):
+                            vals[m] = evaluate(flat[m].contiguous())
+                    if pid < 3:
+                        mask = (vals.abs() < threshold).reshape(n, n, n)[None, None]
+                        mask = upsample(mask.float()).bool()
+                        vals = upsample(vals.reshape(n, n, n)[None, None]).reshape(-1)
+                    threshold /= 2.
+                spacing = tuple((maxs[d] - mins[d]) / (cropN - 1) for d in range(3))
+                yield np.array(mins), spacing, vals.reshape(cropN, cropN, cropN).cpu().numpy().astype(np.float32)

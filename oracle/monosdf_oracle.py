@@ -445,3 +445,50 @@ def probe_loss(out):
         n2 = g2 / (g2.norm(2, dim=1).unsqueeze(-1) + 1e-5)
         loss = loss + 0.005 * torch.norm(n1 - n2, dim=-1).mean()
     return loss
+
+
+# ----------------------------------------------------------------------------
+# inference drivers -- restated for parity tests
+# ----------------------------------------------------------------------------
+def render_image(state, conf, inputs, indices, total_pixels, split_n_pixels=1024,
+                 keys=('rgb_values', 'normal_map', 'depth_values')):
+    """Chunked eval render (utils/general.py:28-58; evaluation/eval.py:105-120)."""
+    outs = []
+    for idx in torch.split(torch.arange(total_pixels), split_n_pixels, dim=0):
+        chunk = dict(inputs)
+        chunk['uv'] = torch.index_select(inputs['uv'], 1, idx)
+        o = render(state, conf, chunk, indices, False, False, None)
+        outs.append({k: o[k].detach() for k in keys})
+    return {k: torch.cat([o[k] for o in outs], 0) for k in keys}
+
+
+def sdf_volume_block(sdf_fn, mins, maxs, cropN):
+    """One block of plots.get_surface_sliding's coarse-to-fine SDF evaluation (utils/plots.py:135-190)."""
+    import numpy as np
+    axes = [torch.tensor(np.linspace(mins[d], maxs[d], cropN)) for d in range(3)]
+    xx, yy, zz = torch.meshgrid(*axes, indexing='ij')
+    pts = torch.vstack([xx.flatten(), yy.flatten(), zz.flatten()]).T.float()
+    pool = torch.nn.AvgPool3d(2, stride=2)
+    up = torch.nn.Upsample(scale_factor=2, mode='nearest')
+    p = pts.reshape(cropN, cropN, cropN, 3).permute(3, 0, 1, 2)
+    pyr = [p]
+    for _ in range(3):
+        p = pool(p[None])[0]
+        pyr.append(p)
+    pyr = pyr[::-1]
+    mask, vals = None, None
+    threshold = 2 * (maxs[0] - mins[0]) / cropN * 8
+    for pid, q in enumerate(pyr):
+        n = q.shape[-1]
+        flat = q.reshape(3, -1).permute(1, 0).contiguous()
+        if mask is None:
+            vals = sdf_fn(flat).reshape(-1)
+        else:
+            m = mask.reshape(-1)
+            if bool(m.any()):
+                vals[m] = sdf_fn(flat[m].contiguous()).reshape(-1)
+        if pid < 3:
+            mask = up((vals.abs() < threshold).reshape(n, n, n)[None, None].float()).bool()
+            vals = up(vals.reshape(n, n, n)[None, None]).reshape(-1)
+        threshold /= 2.
+    return vals.reshape(cropN, cropN, cropN)

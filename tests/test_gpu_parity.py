@@ -231,3 +231,40 @@ def test_full_gradients_against_golden(name):
     for n, ref in c.gdig.items():
         d = digest(params[n].grad)
         assert abs(d[0] - ref[0]) < tol * ref[1] + 1e-9, n
+
+
+def test_full_image_render_chunked():
+    """configs[3] at reduced size: chunked eval render == oracle's chunked render (one pose, uv grid)."""
+    from oracle import monosdf_oracle as mo
+    from monosdf_amd.utils import render
+    c = Case('mlp_w64_image_eval')
+    m = _model(c)
+    n_side = 12
+    ys, xs = torch.meshgrid(torch.arange(n_side), torch.arange(n_side), indexing='ij')
+    uv = torch.stack([xs.flatten() * 30.0 + 10.0, ys.flatten() * 30.0 + 12.0], -1)[None].float()
+    inputs = {'uv': uv, 'pose': c.inputs['pose'], 'intrinsics': c.inputs['intrinsics']}
+    total = n_side * n_side
+    ref = mo.render_image(c.state, c.conf, inputs, c.indices, total, split_n_pixels=50)
+    out = render.render_image(m, _cuda(inputs), c.indices.cuda(), total, split_n_pixels=50)
+    for k in ref:
+        assert out[k].shape == ref[k].shape
+        assert rel_err(out[k], ref[k]) < 5e-4, (k, rel_err(out[k], ref[k]))
+
+
+def test_sdf_volume_coarse_to_fine():
+    """configs[4] at reduced size (one 128^3 block): same volume as the oracle's restatement of
+    plots.get_surface_sliding's SDF loop, up to voxels whose |sdf| sits on a refinement threshold."""
+    from oracle import monosdf_oracle as mo
+    from monosdf_amd.utils import render
+    c = Case('mlp_w64_eval')
+    m = _model(c)
+    st = _oracle_state(c)
+    ref = mo.sdf_volume_block(lambda p: mo.sdf_network_raw(st, c.conf, p)[:, 0], (-1.1,) * 3, (1.1,) * 3, 128)
+    with torch.no_grad():
+        fn = lambda p: m.implicit_network(p)[:, 0]
+        blocks = list(render.sdf_volume(fn, resolution=128, grid_boundary=(-1.1, 1.1), shard=False))
+    assert len(blocks) == 1
+    vol = torch.from_numpy(blocks[0][2])
+    diff = (vol - ref).abs()
+    bad = (diff > 1e-4 * ref.abs().max()).float().mean().item()
+    assert bad < 2e-3, bad
