@@ -59,6 +59,23 @@ int msdf_hash_encode_second_backward(const float* grad, const float* inputs, con
 int msdf_pack_weights(const msdf_plan_t* plan, const msdf_packrule_t* rules_dev, const int* maps_dev,
                       const float* flat_w, const float* flat_b, float* wpack, float* bpack, void* stream);
 
+/* weight normalisation of every layer of a network in one launch (reference: nn.utils.weight_norm hooks,
+ * model/network.py:72-73, 239-240, 381-382).  row_layer_dev[r] = layer index of global row r. */
+typedef struct {
+  const float* v;      /* [rows, cols] weight_v (or the plain weight when has_g == 0) */
+  const float* g;      /* [rows] weight_g */
+  const float* b;      /* [rows] bias */
+  int32_t rows, cols;
+  int32_t w_off;       /* float offset of this layer in the flat weight buffer */
+  int32_t b_off;       /* float offset of this layer in the flat bias buffer */
+  int32_t row_off;     /* first global row of this layer */
+  int32_t has_g;
+} msdf_wn_layer_t;
+int msdf_weightnorm_forward(const msdf_wn_layer_t* layers_dev, const int* row_layer_dev, int total_rows,
+                            float* flat_w, float* flat_b, float* norms, void* stream);
+int msdf_weightnorm_backward(const msdf_wn_layer_t* layers_dev, const int* row_layer_dev, int total_rows,
+                             const float* g_flat_w, const float* norms, float* dv_flat, float* dg_rows, void* stream);
+
 int msdf_sdf_forward(const msdf_plan_t* plan, const float* wpack, const float* bpack, const float* x,
                      const float* aux, int P, float clamp_radius, float sphere_scale, float* sdf, void* stream);
 

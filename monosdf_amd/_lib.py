@@ -94,6 +94,11 @@ class CompositeBwdArgs(C.Structure):
                 ('pose', _P), ('pose_stride', C.c_int32), ('pad_', C.c_int32)]
 
 
+class WnLayer(C.Structure):
+    _fields_ = [('v', _P), ('g', _P), ('b', _P), ('rows', C.c_int32), ('cols', C.c_int32),
+                ('w_off', C.c_int32), ('b_off', C.c_int32), ('row_off', C.c_int32), ('has_g', C.c_int32)]
+
+
 class SamplerArgs(C.Structure):
     _fields_ = [('ray_o', _P), ('ray_d', _P), ('N', C.c_int32), ('M', C.c_int32), ('m_max', C.c_int32),
                 ('n_eval', C.c_int32), ('n_final', C.c_int32), ('n_extra', C.c_int32),
@@ -116,6 +121,8 @@ _SIGNATURES = {
                                   C.c_float, C.c_uint32, C.c_int, _P, _P, _P],
     'msdf_hash_encode_second_backward': [_P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32,
                                          C.c_uint32, C.c_float, C.c_uint32, C.c_int, _P, _P, _P, _P, _P],
+    'msdf_weightnorm_forward': [_P, _P, C.c_int, _P, _P, _P, _P],
+    'msdf_weightnorm_backward': [_P, _P, C.c_int, _P, _P, _P, _P, _P],
     'msdf_pack_weights': [C.POINTER(Plan), _P, _P, _P, _P, _P, _P, _P],
     'msdf_sdf_forward': [C.POINTER(Plan), _P, _P, _P, _P, C.c_int, C.c_float, C.c_float, _P, _P],
     'msdf_sdf_fwd_grad': [C.POINTER(Plan), C.POINTER(FgArgs), _P],

@@ -70,7 +70,12 @@ class _FusedNet(nn.Module):
         if shared is not None:
             return shared
         fused = self._fused(device)
-        flat_w, flat_b = _flat_params(self._layers())
+        wn = getattr(self, '_wn_state', None)
+        if wn is None:
+            wn = ops.WeightNormState()
+            object.__setattr__(self, '_wn_state', wn)
+        # g * v / ||v|| of every layer in one launch (PyTorch autograd still owns weight_g / weight_v / bias)
+        flat_w, flat_b = ops.fused_weight_norm(wn, self._layers())
         wpack, bpack = fused.pack(flat_w, flat_b)
         return fused, flat_w, flat_b, wpack, bpack
 

@@ -82,6 +82,87 @@ class FusedMlp:
 
 
 # ---------------------------------------------------------------------------
+# weight normalisation of a whole network (one launch forward, one backward)
+# ---------------------------------------------------------------------------
+class WeightNormState:
+    """Device tables for msdf_weightnorm_*: rebuilt only when a parameter's storage moves."""
+
+    def __init__(self):
+        self.key = None
+
+    def tables(self, layers):
+        dev = layers[0].bias.device
+        key = tuple((l.weight_v.data_ptr() if l.has_weight_norm else l.weight.data_ptr(),
+                     l.weight_g.data_ptr() if l.has_weight_norm else 0, l.bias.data_ptr()) for l in layers)
+        if key != self.key:
+            recs, row_layer, w_off, b_off = [], [], 0, 0
+            for i, l in enumerate(layers):
+                r = _lib.WnLayer()
+                v = l.weight_v if l.has_weight_norm else l.weight
+                r.v, r.g, r.b = v.data_ptr(), (l.weight_g.data_ptr() if l.has_weight_norm else None), l.bias.data_ptr()
+                r.rows, r.cols = l.out_features, l.in_features
+                r.w_off, r.b_off, r.row_off, r.has_g = w_off, b_off, b_off, int(l.has_weight_norm)
+                recs.append(bytes(r))
+                row_layer += [i] * l.out_features
+                w_off += l.out_features * l.in_features
+                b_off += l.out_features
+            self.layers_dev = torch.from_numpy(np.frombuffer(b''.join(recs), dtype=np.uint8).copy()).to(dev)
+            self.row_layer_dev = torch.tensor(row_layer, dtype=torch.int32, device=dev)
+            self.n_w, self.total_rows = w_off, b_off
+            self.key = key
+        return self
+
+
+class FusedWeightNormFunction(torch.autograd.Function):
+    """(v_0, g_0, b_0, v_1, g_1, b_1, ...) -> (flat effective weights, flat biases)."""
+
+    @staticmethod
+    def forward(ctx, state, layers, *params):
+        st = state.tables(layers)
+        dev = params[0].device
+        flat_w = torch.empty(st.n_w, device=dev, dtype=torch.float32)
+        flat_b = torch.empty(st.total_rows, device=dev, dtype=torch.float32)
+        norms = torch.empty(st.total_rows, device=dev, dtype=torch.float32)
+        _lib.call('msdf_weightnorm_forward', _lib.ptr(st.layers_dev), _lib.ptr(st.row_layer_dev), st.total_rows,
+                  _lib.ptr(flat_w), _lib.ptr(flat_b), _lib.ptr(norms), _lib.stream_ptr())
+        ctx.st, ctx.layers = st, layers
+        ctx.save_for_backward(norms)
+        return flat_w, flat_b
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_w, g_b):
+        st, layers = ctx.st, ctx.layers
+        norms, = ctx.saved_tensors
+        dev = norms.device
+        g_w = g_w.contiguous()
+        dv = torch.empty(st.n_w, device=dev, dtype=torch.float32)
+        dg = torch.empty(st.total_rows, device=dev, dtype=torch.float32)
+        _lib.call('msdf_weightnorm_backward', _lib.ptr(st.layers_dev), _lib.ptr(st.row_layer_dev), st.total_rows,
+                  _lib.ptr(g_w), _lib.ptr(norms), _lib.ptr(dv), _lib.ptr(dg), _lib.stream_ptr())
+        grads, w_off, b_off = [], 0, 0
+        for l in layers:
+            n = l.out_features * l.in_features
+            grads.append(dv[w_off:w_off + n].view(l.out_features, l.in_features))
+            if l.has_weight_norm:
+                grads.append(dg[b_off:b_off + l.out_features].view(l.out_features, 1))
+            grads.append(g_b[b_off:b_off + l.out_features])
+            w_off += n
+            b_off += l.out_features
+        return (None, None) + tuple(grads)
+
+
+def fused_weight_norm(state, layers):
+    params = []
+    for l in layers:
+        params.append(l.weight_v if l.has_weight_norm else l.weight)
+        if l.has_weight_norm:
+            params.append(l.weight_g)
+        params.append(l.bias)
+    return FusedWeightNormFunction.apply(state, layers, *params)
+
+
+# ---------------------------------------------------------------------------
 # SDF network
 # ---------------------------------------------------------------------------
 def sdf_forward_nograd(mlp, wpack, bpack, x, aux, clamp_radius, sphere_scale):
