@@ -145,15 +145,20 @@ def main():
     torch.manual_seed(0)                      # same initial weights on every rank (as DDP would broadcast)
     model = MonoSDFNetwork(model_conf(grid=(args.config == 'grid'))).to(device).train()
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.Adam(params, lr=5e-4)
+    try:
+        opt = torch.optim.Adam(params, lr=5e-4, fused=True)      # one multi-tensor launch for the whole update
+    except (RuntimeError, TypeError):
+        opt = torch.optim.Adam(params, lr=5e-4)
     torch.manual_seed(1234 + rank)            # per-rank sampling noise
     rays = make_rays(N_RAYS, 1 + rank, device)
     indices = torch.arange(N_RAYS, device=device)
 
+    from monosdf_amd import ops
+
     def step():
         opt.zero_grad(set_to_none=True)
         out = model(rays, indices, if_pixel_input=True)
-        loss = probe_loss(out)
+        loss = ops.probe_loss(out)        # the BASELINE.md probe loss, value + gradients in one HIP launch
         loss.backward()
         if world > 1:
             flat = torch.cat([p.grad.reshape(-1) for p in params])

@@ -209,6 +209,20 @@ typedef struct {
 } msdf_composite_bwd_args_t;
 int msdf_composite_backward(const msdf_composite_bwd_args_t* args, void* stream);
 
+/* ---- fused benchmark loss: value partials + all gradients in one pass ---- */
+typedef struct {
+  const float* rgb;      /* [N,3] rgb_values */
+  const float* nrm;      /* [N,3] normal_map */
+  const float* depth;    /* [N] depth_values */
+  const float* g1;       /* [M,3] grad_theta */
+  const float* g2;       /* [M,3] grad_theta_nei */
+  int32_t N, M;
+  float w_normal, w_depth, w_eik, w_smooth;
+  float* g_rgb; float* g_nrm; float* g_depth; float* g_g1; float* g_g2;   /* d loss / d input */
+  float* partial;        /* [ceil(max(N,M)/256)] per-block loss partial sums */
+} msdf_probe_loss_args_t;
+int msdf_probe_loss(const msdf_probe_loss_args_t* args, void* stream);
+
 /* ---- error-bounded sampler (reference: model/ray_sampler.py:48-83, 110-272) ---- */
 typedef struct {
   const float* ray_o;        /* [N,3] */
@@ -239,7 +253,9 @@ typedef struct {
   const int64_t* eik_idx;    /* [N] or NULL */
   float* z_out;              /* [N, n_final + n_extra + 2] */
   float* z_eik;              /* [N] or NULL */
-  float* pts_out;            /* [N * S, 3] or NULL */
+  float* pts_out;            /* [N * S (+ 4 N), 3] or NULL: ray samples, then (training) the eikonal points */
+  const float* eik_uniform;  /* [N,3] uniform points in the bounding cube, or NULL (no eikonal block) */
+  const float* nei_rand;     /* [2N,3] U[0,1) jitter of the neighbour points (reference network.py:583-594) */
 } msdf_sampler_args_t;
 int msdf_sampler_init(const msdf_sampler_args_t* args, void* stream);
 int msdf_sampler_beta(const msdf_sampler_args_t* args, void* stream);

@@ -99,6 +99,12 @@ class WnLayer(C.Structure):
                 ('w_off', C.c_int32), ('b_off', C.c_int32), ('row_off', C.c_int32), ('has_g', C.c_int32)]
 
 
+class ProbeLossArgs(C.Structure):
+    _fields_ = [('rgb', _P), ('nrm', _P), ('depth', _P), ('g1', _P), ('g2', _P), ('N', C.c_int32), ('M', C.c_int32),
+                ('w_normal', C.c_float), ('w_depth', C.c_float), ('w_eik', C.c_float), ('w_smooth', C.c_float),
+                ('g_rgb', _P), ('g_nrm', _P), ('g_depth', _P), ('g_g1', _P), ('g_g2', _P), ('partial', _P)]
+
+
 class SamplerArgs(C.Structure):
     _fields_ = [('ray_o', _P), ('ray_d', _P), ('N', C.c_int32), ('M', C.c_int32), ('m_max', C.c_int32),
                 ('n_eval', C.c_int32), ('n_final', C.c_int32), ('n_extra', C.c_int32),
@@ -107,7 +113,8 @@ class SamplerArgs(C.Structure):
                 ('eps', C.c_float), ('add_tiny', C.c_float), ('lemma', C.c_float),
                 ('beta0', _P), ('z', _P), ('sdf', _P), ('new_z', _P), ('new_sdf', _P), ('new_pos', _P),
                 ('pts', _P), ('beta', _P), ('flag', _P), ('jitter', _P), ('u_final', _P), ('final_z', _P),
-                ('extra_idx', _P), ('eik_idx', _P), ('z_out', _P), ('z_eik', _P), ('pts_out', _P)]
+                ('extra_idx', _P), ('eik_idx', _P), ('z_out', _P), ('z_eik', _P), ('pts_out', _P),
+                ('eik_uniform', _P), ('nei_rand', _P)]
 
 
 _ERR = {1: 'invalid argument', 2: 'kernel launch failed', 3: 'unsupported configuration'}
@@ -133,6 +140,7 @@ _SIGNATURES = {
     'msdf_reduce': [_P, C.c_int, _P, _P, _P, _P],
     'msdf_composite_forward': [C.POINTER(CompositeArgs), _P],
     'msdf_composite_backward': [C.POINTER(CompositeBwdArgs), _P],
+    'msdf_probe_loss': [C.POINTER(ProbeLossArgs), _P],
     'msdf_sampler_init': [C.POINTER(SamplerArgs), _P],
     'msdf_sampler_beta': [C.POINTER(SamplerArgs), _P],
     'msdf_sampler_resample': [C.POINTER(SamplerArgs), _P],

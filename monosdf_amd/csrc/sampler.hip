@@ -344,9 +344,23 @@ __global__ void __launch_bounds__(64 * SMP_WAVES) smp_finish_k(const SmpArgs a) 
     }
   }
   smp_sync();
-  if (lane == 0 && a.z_eik != nullptr) {
+  if (lane == 0) {
     const int idx = (a.eik_idx != nullptr) ? (int)a.eik_idx[ray] : 0;
-    a.z_eik[ray] = sorted[idx];
+    const float ze = sorted[idx];
+    if (a.z_eik != nullptr) a.z_eik[ray] = ze;
+    if (a.pts_out != nullptr && a.eik_uniform != nullptr) {
+      // eikonal block (reference network.py:583-594): [uniform | near-surface | their jittered neighbours]
+      float* e = a.pts_out + (size_t)a.N * S * 3;
+      const float od[3] = {o0 + ze * d0, o1 + ze * d1, o2 + ze * d2};
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float u = a.eik_uniform[(size_t)ray * 3 + c];
+        e[((size_t)ray) * 3 + c] = u;
+        e[((size_t)a.N + ray) * 3 + c] = od[c];
+        e[((size_t)2 * a.N + ray) * 3 + c] = u + (a.nei_rand[(size_t)ray * 3 + c] - 0.5f) * 0.01f;
+        e[((size_t)3 * a.N + ray) * 3 + c] = od[c] + (a.nei_rand[((size_t)a.N + ray) * 3 + c] - 0.5f) * 0.01f;
+      }
+    }
   }
 }
 

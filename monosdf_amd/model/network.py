@@ -354,24 +354,11 @@ class MonoSDFNetwork(nn.Module):
         net.share(device)
         self.rendering_network.share(device)
         try:
-            z_vals, z_samples_eik = self.ray_sampler.get_z_vals(ray_dirs, cam_loc, self)
+            # the sampler's last kernel also writes the sample points and (training) the eikonal points
+            z_vals, z_samples_eik, x_all = self.ray_sampler.sample(ray_dirs, cam_loc, self)
             N, S = z_vals.shape
-            points_flat = (cam_loc.unsqueeze(1) + z_vals.unsqueeze(2) * ray_dirs.unsqueeze(1)).reshape(-1, 3)
             P = N * S
-            x_all = points_flat
-            if self.training:
-                n_eik = batch_size * num_pixels
-                R = self.scene_bounding_sphere
-                eik_uniform = noise.get('eik_uniform')
-                if eik_uniform is None:
-                    eik_uniform = torch.empty(n_eik, 3, device=device).uniform_(-R, R)
-                eik_near = (cam_loc.unsqueeze(1) + z_samples_eik.unsqueeze(2) * ray_dirs.unsqueeze(1)).reshape(-1, 3)
-                eik = torch.cat([eik_uniform.to(device), eik_near], 0)
-                nei = noise.get('nei_rand')
-                if nei is None:
-                    nei = torch.rand_like(eik)
-                eik = torch.cat([eik, eik + (nei.to(device) - 0.5) * 0.01], 0)
-                x_all = torch.cat([points_flat, eik], 0)
+            points_flat = x_all[:P]
             # one fused evaluation for the ray samples (clamped, with features) and the eikonal points
             sdf_all, feature_vectors, grad_all = net.evaluate(x_all, P, P, save=torch.is_grad_enabled())
             sdf, gradients_sdf = sdf_all[:P], grad_all[:P]

@@ -35,6 +35,12 @@ class ErrorBoundSampler(RaySampler):
         self._lemma = float(1.0 / (4.0 * torch.log(torch.tensor(self.eps + 1.0))))
 
     def get_z_vals(self, ray_dirs, cam_loc, model):
+        z, z_eik, _ = self.sample(ray_dirs, cam_loc, model, want_points=False)
+        return z, z_eik
+
+    def sample(self, ray_dirs, cam_loc, model, want_points=True):
+        """get_z_vals plus (optionally) the 3-D points of the ray samples and, in training, the eikonal
+        points appended behind them -- written by the finish kernel instead of ~15 small tensor ops."""
         dev = ray_dirs.device
         if not ray_dirs.is_cuda:
             raise RuntimeError('monosdf_amd: the sampler runs on the GPU only (no CPU fallback)')
@@ -112,5 +118,18 @@ class ErrorBoundSampler(RaySampler):
         a.M = M
         a.extra_idx, a.eik_idx = extra_idx.data_ptr(), eik_idx.data_ptr()
         a.z_out, a.z_eik, a.pts_out = z_out.data_ptr(), z_eik.data_ptr(), None
+        x_all = None
+        if want_points:
+            n_eik = 4 * N if training else 0
+            x_all = torch.empty(N * S + n_eik, 3, **f32)
+            a.pts_out = x_all.data_ptr()
+            if training:
+                R = self.scene_bounding_sphere
+                eik_uniform = noise.get('eik_uniform')
+                eik_uniform = (torch.empty(N, 3, **f32).uniform_(-R, R) if eik_uniform is None
+                               else eik_uniform.to(**f32).contiguous())
+                nei = noise.get('nei_rand')
+                nei = torch.rand(2 * N, 3, **f32) if nei is None else nei.to(**f32).contiguous()
+                a.eik_uniform, a.nei_rand = eik_uniform.data_ptr(), nei.data_ptr()
         _lib.call('msdf_sampler_finish', C.byref(a), st)
-        return z_out, z_eik
+        return z_out, z_eik, x_all

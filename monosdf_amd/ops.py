@@ -503,3 +503,41 @@ class HashEncodeWithJacobian(torch.autograd.Function):
         grad = grad.view(B, L, Cdim).permute(1, 0, 2).contiguous()
         _, g_emb = HashEncodeBackwardFunction.apply(grad, inputs, embeddings, offsets, dy_dx, ctx.dims, False, True)
         return None, g_emb, None, None, None
+
+
+# ---------------------------------------------------------------------------
+# fused benchmark loss (value + gradients in one launch)
+# ---------------------------------------------------------------------------
+class ProbeLossFunction(torch.autograd.Function):
+    """mean|rgb| + w_n mean|normal| + w_d mean depth + w_e mean (|g1|-1)^2 + w_s mean |n1 - n2|  (BASELINE.md 2)."""
+
+    @staticmethod
+    def forward(ctx, rgb, nrm, depth, g1, g2, w_normal, w_depth, w_eik, w_smooth):
+        rgb, nrm = _need_cuda(rgb.detach(), 'rgb_values'), _need_cuda(nrm.detach(), 'normal_map')
+        depth = _need_cuda(depth.detach(), 'depth_values').reshape(-1)
+        g1, g2 = _need_cuda(g1.detach(), 'grad_theta'), _need_cuda(g2.detach(), 'grad_theta_nei')
+        N, M = rgb.shape[0], g1.shape[0]
+        dev = rgb.device
+        outs = [torch.empty_like(t) for t in (rgb, nrm, depth, g1, g2)]
+        partial = torch.empty((max(N, M) + 255) // 256, device=dev, dtype=torch.float32)
+        a = _lib.ProbeLossArgs()
+        a.rgb, a.nrm, a.depth, a.g1, a.g2 = [t.data_ptr() for t in (rgb, nrm, depth, g1, g2)]
+        a.N, a.M = N, M
+        a.w_normal, a.w_depth, a.w_eik, a.w_smooth = float(w_normal), float(w_depth), float(w_eik), float(w_smooth)
+        a.g_rgb, a.g_nrm, a.g_depth, a.g_g1, a.g_g2 = [t.data_ptr() for t in outs]
+        a.partial = partial.data_ptr()
+        _lib.call('msdf_probe_loss', C.byref(a), _lib.stream_ptr())
+        ctx.save_for_backward(*outs)
+        ctx.depth_shape = None
+        return partial.sum()
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        g_rgb, g_nrm, g_depth, g_g1, g_g2 = ctx.saved_tensors
+        return (g_rgb * g, g_nrm * g, (g_depth * g).reshape(-1, 1), g_g1 * g, g_g2 * g, None, None, None, None)
+
+
+def probe_loss(out, w_normal=0.05, w_depth=0.1, w_eik=0.05, w_smooth=0.005):
+    return ProbeLossFunction.apply(out['rgb_values'], out['normal_map'], out['depth_values'], out['grad_theta'],
+                                   out['grad_theta_nei'], w_normal, w_depth, w_eik, w_smooth)

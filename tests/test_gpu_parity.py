@@ -268,3 +268,22 @@ def test_sdf_volume_coarse_to_fine():
     diff = (vol - ref).abs()
     bad = (diff > 1e-4 * ref.abs().max()).float().mean().item()
     assert bad < 2e-3, bad
+
+
+def test_fused_probe_loss_matches_torch_autograd():
+    from oracle import monosdf_oracle as mo
+    from monosdf_amd import ops
+    g = torch.Generator().manual_seed(21)
+    N = 300
+    vals = {'rgb_values': torch.rand(N, 3, generator=g) - 0.3, 'normal_map': torch.randn(N, 3, generator=g),
+            'depth_values': torch.rand(N, 1, generator=g) + 0.5, 'grad_theta': torch.randn(2 * N, 3, generator=g),
+            'grad_theta_nei': torch.randn(2 * N, 3, generator=g)}
+    ref_in = {k: v.clone().requires_grad_(True) for k, v in vals.items()}
+    l_ref = mo.probe_loss(ref_in)
+    g_ref = torch.autograd.grad(l_ref, list(ref_in.values()))
+    gpu_in = {k: v.cuda().requires_grad_(True) for k, v in vals.items()}
+    l = ops.probe_loss(gpu_in)
+    assert abs(l.item() - l_ref.item()) < 1e-5 * abs(l_ref.item())
+    (2.0 * l).backward()
+    for (k, t), gr in zip(gpu_in.items(), g_ref):
+        assert rel_err(t.grad, 2.0 * gr) < 1e-5, k

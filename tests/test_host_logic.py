@@ -43,7 +43,8 @@ def test_struct_sizes_match_header():
              'msdf_fg_args_t': _lib.FgArgs, 'msdf_bw_args_t': _lib.BwArgs,
              'msdf_color_fwd_args_t': _lib.ColorFwdArgs, 'msdf_color_bwd_args_t': _lib.ColorBwdArgs,
              'msdf_composite_args_t': _lib.CompositeArgs, 'msdf_composite_bwd_args_t': _lib.CompositeBwdArgs,
-             'msdf_sampler_args_t': _lib.SamplerArgs, 'msdf_wn_layer_t': _lib.WnLayer}
+             'msdf_sampler_args_t': _lib.SamplerArgs, 'msdf_wn_layer_t': _lib.WnLayer,
+             'msdf_probe_loss_args_t': _lib.ProbeLossArgs}
     src = '#include <stdio.h>\n#include "monosdf_hip.h"\nint main(){' + ''.join(
         'printf("%s %%zu\\n", sizeof(%s));' % (n, n) for n in names) + 'return 0;}'
     with tempfile.TemporaryDirectory() as d:
