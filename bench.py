@@ -135,11 +135,12 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get('MSDF_FORCE_DIST') == '1'    # the env knob exercises RCCL on one GPU
+    if use_dist:
         import torch.distributed as dist
-        dist.init_process_group(backend='nccl', init_method='env://')
+        dist.init_process_group(backend='nccl', init_method='env://', device_id=device)
 
-    from monosdf_amd import _lib
+    from monosdf_amd import _lib, parallel
     from monosdf_amd.model.network import MonoSDFNetwork
 
     torch.manual_seed(0)                      # same initial weights on every rank (as DDP would broadcast)
@@ -160,14 +161,7 @@ def main():
         out = model(rays, indices, if_pixel_input=True)
         loss = ops.probe_loss(out)        # the BASELINE.md probe loss, value + gradients in one HIP launch
         loss.backward()
-        if world > 1:
-            flat = torch.cat([p.grad.reshape(-1) for p in params])
-            dist.all_reduce(flat)
-            flat /= world
-            off = 0
-            for p in params:
-                p.grad.copy_(flat[off:off + p.numel()].view_as(p.grad))
-                off += p.numel()
+        parallel.average_gradients(params)        # one flat RCCL all-reduce (no-op on one GPU)
         opt.step()
         return loss
 
@@ -176,8 +170,8 @@ def main():
     rounds = model.ray_sampler.last_rounds
 
     def barrier():
-        if world > 1:
-            dist.barrier()
+        if use_dist:
+            dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     _lib.PROFILE = {}
@@ -188,7 +182,7 @@ def main():
     barrier()
     dt = time.time() - t0
     prof, _lib.PROFILE = _lib.PROFILE, None
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -209,7 +203,7 @@ def main():
         }
         if args.config == 'grid':
             print(json.dumps(grid_report(args, kern, dt, world, rounds, float(loss.item()))))
-            if world > 1:
+            if use_dist:
                 dist.destroy_process_group()
             return
         dom = max((n for n in kern if n in flops), key=lambda n: kern[n]['ms_per_step'])
@@ -232,7 +226,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline()
         print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -15,24 +15,36 @@
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 #define WG_THREADS 512
-#define WG_NP 32                               // points per LDS stage
+#define WG_NP 16                               // points per LDS stage
+#define WG_NBUF 4                              // LDS ring: 3 stages in flight behind the one being read
 #define WG_TILE_F (WG_NP * 256)                // floats per operand tile
 #define WG_STAGE_F (2 * WG_TILE_F + 64)        // X tile, Y tile, v[NP] (+pad)
-#define WG_LDS_BYTES (2 * WG_STAGE_F * 4)
+#define WG_LDS_BYTES (WG_NBUF * WG_STAGE_F * 4)
+#define WG_GLDS_PER_STAGE 5                    // LDS-DMA instructions every wave issues per stage (uniform!)
 
+// Copy [WG_NP x w] (row pitch ld) into a dense LDS image with exactly TWO 1 KB LDS-DMA pieces per wave;
+// a wave whose piece index runs past the tile re-copies the last piece (same bytes, same place), which
+// keeps the per-wave instruction count uniform so that a counted s_waitcnt vmcnt(N) is exact.
 __device__ __forceinline__ void wg_issue_tile(const float* __restrict__ src, const int ld, const int w,
-                                              float* dst) {
-  // copy [WG_NP x w] (row pitch ld) into a dense LDS image, 16 B per lane, 1 KB per wave-instruction
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
+                                              float* dst, const int wave, const int lane) {
   const int w4 = w >> 2;
-  const int units = WG_NP * w4;                // float4 units, a multiple of 64 (w multiple of 16, NP = 32)
-  const int pieces = units >> 6;
-  for (int piece = wave; piece < pieces; piece += WG_THREADS / 64) {
+  const int pieces = (WG_NP * w4) >> 6;        // >= 1 (w multiple of 16, NP = 16)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int piece = min(wave + 8 * i, pieces - 1);
     const int u = piece * 64 + lane;
     const int row = u / w4, c4 = u - row * w4;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)row * ld + 4 * c4),
                                      (__attribute__((address_space(3))) void*)(dst + piece * 256), 16, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void wg_wait_outstanding(const int stages_behind) {
+  // wait until at most `stages_behind` later stages are still in flight
+  switch (stages_behind) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
   }
 }
 
@@ -58,6 +70,7 @@ msdf_wgrad_k(const msdf_wgrad_item_t* __restrict__ items, const int* __restrict_
   const int per = (n_stages_total + n_splits - 1) / n_splits;
   const int s_begin = split * per;
   const int s_end = min(n_stages_total, s_begin + per);
+  const int n_st = max(0, s_end - s_begin);
 
   const float* X = ws + it.x_off;
   const float* Y = ws + it.y_off;
@@ -81,26 +94,31 @@ msdf_wgrad_k(const msdf_wgrad_item_t* __restrict__ items, const int* __restrict_
   for (int b = 0; b < 2; ++b) bj[b] = (j_base + 32 * b) < it.wy;
   const bool wave_active = do_mm && ai[0] && bj[0];
 
-  auto issue = [&](int stage, int buf) {
-    float* base = lds_f + buf * WG_STAGE_F;
-    const size_t p0 = (size_t)stage * WG_NP;
-    wg_issue_tile(X + p0 * it.x_ld, it.x_ld, it.wx, base);
-    if (do_mm) wg_issue_tile(Y + p0 * it.y_ld, it.y_ld, it.wy, base + WG_TILE_F);
-    if (V != nullptr && tid < WG_NP) base[2 * WG_TILE_F + tid] = V[p0 + tid];
+  // every wave issues exactly WG_GLDS_PER_STAGE LDS-DMA instructions per stage
+  auto issue = [&](int j) {
+    float* base = lds_f + (j & (WG_NBUF - 1)) * WG_STAGE_F;
+    const size_t p0 = (size_t)(s_begin + j) * WG_NP;
+    wg_issue_tile(X + p0 * it.x_ld, it.x_ld, it.wx, base, wave, lane);
+    if (do_mm) wg_issue_tile(Y + p0 * it.y_ld, it.y_ld, it.wy, base + WG_TILE_F, wave, lane);
+    else wg_issue_tile(X + p0 * it.x_ld, it.x_ld, it.wx, base, wave, lane);
+    // per-point scalar (or, without one, a re-copy of 64 floats of X): one 4-byte-per-lane piece
+    const float* vsrc = (V != nullptr) ? V + p0 + min(lane, WG_NP - 1) : X + p0 * it.x_ld + min(lane, 15);
+    float* vdst = (V != nullptr) ? base + 2 * WG_TILE_F : base + 2 * WG_TILE_F;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vsrc,
+                                     (__attribute__((address_space(3))) void*)vdst, 4, 0, 0);
   };
 
-  // Every workgroup walks its stages from a different starting phase (and wraps around): the streams of
-  // the ~250 workgroups are laid out at equal strides, and walking them in lockstep would keep them all
-  // on the same HBM channels.  The summation order inside a workgroup stays fixed (deterministic).
-  const int n_st = max(0, s_end - s_begin);
-  const int rot = (n_st > 0) ? (int)((blockIdx.x * 0x9E3779B1u) >> 8) % n_st : 0;
-  auto stage_of = [&](int j) { int t = j + rot; if (t >= n_st) t -= n_st; return s_begin + t; };
-  if (n_st > 0) issue(stage_of(0), 0);
-  __syncthreads();
+  // prologue: up to 3 stages in flight
+#pragma unroll
+  for (int j = 0; j < WG_NBUF - 1; ++j)
+    if (j < n_st) issue(j);
+
   for (int j = 0; j < n_st; ++j) {
-    const int buf = j & 1;
-    if (j + 1 < n_st) issue(stage_of(j + 1), buf ^ 1);
-    const float* xt = lds_f + buf * WG_STAGE_F;
+    // stage j has landed once at most min(2, n_st-1-j) later stages are outstanding
+    wg_wait_outstanding(min(WG_NBUF - 2, n_st - 1 - j));
+    __builtin_amdgcn_s_barrier();              // every wave's pieces of stage j are in LDS; stage j-1 is fully consumed
+    if (j + WG_NBUF - 1 < n_st) issue(j + WG_NBUF - 1);   // refill the buffer stage j-1 used
+    const float* xt = lds_f + (j & (WG_NBUF - 1)) * WG_STAGE_F;
     const float* yt = xt + WG_TILE_F;
     const float* vt = xt + 2 * WG_TILE_F;
     if (wave_active) {
@@ -143,7 +161,6 @@ msdf_wgrad_k(const msdf_wgrad_item_t* __restrict__ items, const int* __restrict_
 #pragma unroll 8
       for (int p = 0; p < WG_NP; ++p) vrow += vt[p] * yt[p * it.wy + (tid - 256)];
     }
-    __syncthreads();
   }
 
   // ---------------- write this split's partials ----------------

@@ -32,10 +32,7 @@ def run(split_fn, label, iters=5):
     ms = e0.elapsed_time(e1) / iters
     print('%-28s WGs %4d  %.3f ms  %.1f TFLOP/s' % (label, wg_map.numel() // 2, ms, 2 * macs / ms / 1e9))
 
-n_stages = P_pad // 32
 prog = planlib.balanced_program(planlib.build_sdf_wgrad, mp, P_pad)
 print('balanced: WGs', len(prog.wg_map()) // 2, sorted(set((it['weight'], it['n_splits']) for it in prog.items)))
-for S in (14, 16, 29, 32, 44, 64):
-    run(lambda w, S=S: max(1, int(round(S * max(w, 0.3)))), 'weighted S=%d' % S)
-for S in (32, 64):
+for S in (16, 32, 48, 64, 96, 128):
     run(lambda w, S=S: S, 'all items S=%d' % S)
