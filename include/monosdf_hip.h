@@ -79,6 +79,13 @@ int msdf_weightnorm_backward(const msdf_wn_layer_t* layers_dev, const int* row_l
 int msdf_sdf_forward(const msdf_plan_t* plan, const float* wpack, const float* bpack, const float* x,
                      const float* aux, int P, float clamp_radius, float sphere_scale, float* sdf, void* stream);
 
+/* bf16x3 variants (a*b ~ a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the bf16 matrix cores, fp32 accumulate):
+ * `plan` carries K-block counts in ktp/otp and 16-byte pack offsets (monosdf_amd/plan.py build_b16). */
+int msdf_pack_weights_b16(const msdf_plan_t* plan, const msdf_packrule_t* rules_dev, const int* maps_dev,
+                          const float* flat_w, const float* flat_b, void* wpack, float* bpack, void* stream);
+int msdf_sdf_forward_b16(const msdf_plan_t* plan, const void* wpack, const float* bpack, const float* x,
+                         const float* aux, int P, float clamp_radius, float sphere_scale, float* sdf, void* stream);
+
 typedef struct {
   const float* wpack;
   const float* bpack;

@@ -48,6 +48,19 @@ class FusedMlp:
                   _lib.ptr(flat_w), _lib.ptr(flat_b), _lib.ptr(wpack), _lib.ptr(bpack), _lib.stream_ptr())
         return wpack, bpack
 
+    def pack_b16(self, flat_w, flat_b):
+        """bf16 hi/lo packs for the bf16x3 kernels."""
+        mp = self.mp
+        if not hasattr(mp, 'plan16'):
+            mp.build_b16()
+        flat_w = _need_cuda(flat_w.detach(), 'weights')
+        flat_b = _need_cuda(flat_b.detach(), 'biases')
+        wpack = torch.empty(mp.wpack16_v8 * 4 + 4 * 9 * 2 * 64 * 4, device=self.device, dtype=torch.float32)
+        bpack = torch.empty(mp.bpack_f + 64, device=self.device, dtype=torch.float32)
+        _lib.call('msdf_pack_weights_b16', C.byref(mp.plan16), _lib.ptr(self.rules_dev), _lib.ptr(self.maps_dev),
+                  _lib.ptr(flat_w), _lib.ptr(flat_b), _lib.ptr(wpack), _lib.ptr(bpack), _lib.stream_ptr())
+        return wpack, bpack
+
     # -- weight gradients ----------------------------------------------------------
     def wgrad_program(self, P_pad):
         key = P_pad
@@ -165,13 +178,15 @@ def fused_weight_norm(state, layers):
 # ---------------------------------------------------------------------------
 # SDF network
 # ---------------------------------------------------------------------------
-def sdf_forward_nograd(mlp, wpack, bpack, x, aux, clamp_radius, sphere_scale):
-    """get_sdf_vals: forward only (sampler)."""
+def sdf_forward_nograd(mlp, wpack, bpack, x, aux, clamp_radius, sphere_scale, b16=False):
+    """get_sdf_vals: forward only (sampler).  b16: bf16x3 kernel with packs from FusedMlp.pack_b16."""
     x = _need_cuda(x, 'points')
     P = x.shape[0]
     out = torch.empty(P, 1, device=x.device, dtype=torch.float32)
-    _lib.call('msdf_sdf_forward', C.byref(mlp.mp.plan), _lib.ptr(wpack), _lib.ptr(bpack), _lib.ptr(x),
-              _lib.ptr(aux), P, float(clamp_radius), float(sphere_scale), _lib.ptr(out), _lib.stream_ptr())
+    plan = mlp.mp.plan16 if b16 else mlp.mp.plan
+    _lib.call('msdf_sdf_forward_b16' if b16 else 'msdf_sdf_forward', C.byref(plan), _lib.ptr(wpack), _lib.ptr(bpack),
+              _lib.ptr(x), _lib.ptr(aux), P, float(clamp_radius), float(sphere_scale), _lib.ptr(out),
+              _lib.stream_ptr())
     return out
 
 

@@ -84,6 +84,24 @@ class MlpPlan:
         self.colmaps.append((r.colmap_off, colmap))
         return u
 
+    def build_b16(self):
+        """Second plan for the bf16x3 kernels: ktp / otp = K-block counts (32 slots), wf_off / wb_off =
+        16-byte offsets of the hi/lo packs; everything else identical."""
+        import copy
+        p16 = _lib.Plan()
+        C.memmove(C.byref(p16), C.byref(self.plan), C.sizeof(_lib.Plan))
+        off = 0
+        for u in range(self.plan.n_layers):
+            L = p16.layer[u]
+            L.ktp, L.otp = (L.kt + 1) // 2, (L.ot + 1) // 2
+            L.wf_off = off
+            off += _even(L.ot) * L.ktp * 2 * 64
+            L.wb_off = off
+            off += _even(L.kt) * L.otp * 2 * 64
+        self.plan16 = p16
+        self.wpack16_v8 = off
+        return p16
+
     def finalise(self):
         # flat weight / bias buffers are the concatenation of the original tensors
         w_off = np.cumsum([0] + [r * c for r, c in self.w_shapes])
