@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libmonosdf_hip.so')
+# MONOSDF_HIP_LIB: another build of the same library (kernel tuning experiments), never a different backend
+LIB_PATH = os.environ.get('MONOSDF_HIP_LIB') or os.path.join(_HERE, 'libmonosdf_hip.so')
 
 MAX_LAYERS = 10
 MAX_TILES = 17

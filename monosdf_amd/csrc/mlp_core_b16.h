@@ -13,11 +13,21 @@
 // hi plane then lo plane (1 KB each).
 #pragma once
 #include "mlp_core.h"
+#ifndef B16_EXP
+#define B16_EXP 0   // tuning experiments only (scripts/bench_b16.py); 0 = product code
+#endif
 
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 
 #define KB_MAX ((MT + 1) / 2)                       // 9 k-blocks of 32 slots
-#define B16_BUF_V8 (CHUNK_OT * KB_MAX * 2 * 64)     // v8bf (16 B) per LDS buffer: 36 KB
+// The bf16 matrix cores consume weights 5.3x faster than the fp32 ones, so the L2 -> LDS weight stream,
+// not the MFMA pipe, sizes the workgroup: 8 waves (128 points) share every chunk, one workgroup per CU,
+// 4 out tiles per chunk (72 KB per buffer, double buffered).
+#define B16_WAVES 8
+#define B16_THREADS (64 * B16_WAVES)
+#define B16_PTS_PER_WG (16 * B16_WAVES)
+#define B16_CHUNK_OT 4
+#define B16_BUF_V8 (B16_CHUNK_OT * KB_MAX * 2 * 64) // v8bf (16 B) per LDS buffer: 72 KB
 #define B16_LDS_BYTES (2 * B16_BUF_V8 * 16)
 
 struct B16Act {           // an activation vector as MFMA B operands
@@ -53,8 +63,8 @@ __device__ __forceinline__ void b16_chunk_issue(const v8bf* __restrict__ src, v8
   const int lane = threadIdx.x & 63;
   const int pieces = n_v8 >> 6;
 #pragma unroll
-  for (int i = 0; i < (PIECES_MAX + 3) / 4; ++i) {
-    const int piece = wave + 4 * i;
+  for (int i = 0; i < (PIECES_MAX + B16_WAVES - 1) / B16_WAVES; ++i) {
+    const int piece = wave + B16_WAVES * i;
     if (piece < pieces) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 64 + lane),
                                        (__attribute__((address_space(3))) void*)(dst + piece * 64), 16, 0, 0);
@@ -62,73 +72,113 @@ __device__ __forceinline__ void b16_chunk_issue(const v8bf* __restrict__ src, v8
   }
 }
 
-// acc[0..OT) += W * act;  W = bf16 hi/lo pack [ceil2(OT)][KB][2][64] v8bf;  KB_T > 0: compile-time K-block count.
-template <int KB_T>
+struct B16NoEpilogue {
+  __device__ __forceinline__ void operator()(const int, v4f&) const {}
+};
+
+// one out tile against all K blocks (runtime K-block count): c += W[ot] * act (3 MFMAs per K block)
+__device__ __forceinline__ v4f b16_tile_dyn(v4f c, const v8bf* __restrict__ w, const B16Act& act, const int KB) {
+  v8bf ah = w[0], al = w[64];
+#pragma unroll
+  for (int kb = 0; kb < KB_MAX; ++kb) {
+    if (kb < KB) {
+      v8bf nh = ah, nl = al;
+      if (kb + 1 < KB_MAX && kb + 1 < KB) {
+        nh = w[(kb + 1) * 128];
+        nl = w[(kb + 1) * 128 + 64];
+      }
+      __builtin_amdgcn_sched_barrier(0);     // keep the prefetch of the next fragments above the MFMAs
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, act.hi[kb], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, act.lo[kb], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, act.hi[kb], c, 0, 0, 0);
+      ah = nh;
+      al = nl;
+    }
+  }
+  return c;
+}
+
+// acc[0..OT) += W * act;  W = bf16 hi/lo pack [ceil4(OT)][KB][2][64] v8bf;  KB_T > 0: compile-time K-block count.
+// epi(t, acc[t]) runs as soon as out tile t is complete, i.e. between the matrix products of neighbouring
+// tiles: the activation's VALU work overlaps the other wave's MFMAs instead of forming a phase of its own.
+// All B16_THREADS threads of the workgroup call this together (barriers inside).
+template <int KB_T, class Epi>
 __device__ __forceinline__ void gemm_b16(v4f (&acc)[MT], const B16Act& act, const int OT, const int kb_rt,
-                                         const v8bf* __restrict__ wsrc, v8bf* lds) {
+                                         const v8bf* __restrict__ wsrc, v8bf* lds, const Epi& epi) {
   constexpr bool DYN = (KB_T == 0);
   constexpr int KMAX = DYN ? KB_MAX : KB_T;
   const int KB = DYN ? kb_rt : KB_T;
-  const int ch_v8 = CHUNK_OT * KB * 2 * 64;
+  const int ch_v8 = B16_CHUNK_OT * KB * 2 * 64;
   const int lane = threadIdx.x & 63;
-  const int nchunks = (OT + CHUNK_OT - 1) / CHUNK_OT;
-  b16_chunk_issue<CHUNK_OT * KMAX * 2>(wsrc, lds, ch_v8);
+  const int nchunks = (OT + B16_CHUNK_OT - 1) / B16_CHUNK_OT;
+  b16_chunk_issue<B16_CHUNK_OT * KMAX * 2>(wsrc, lds, ch_v8);
   __syncthreads();
 #pragma unroll
-  for (int c = 0; c < (MT + 1) / 2; ++c) {
+  for (int c = 0; c < (MT + B16_CHUNK_OT - 1) / B16_CHUNK_OT; ++c) {
     if (c < nchunks) {
       const int buf = c & 1;
+#if B16_EXP == 3
+      if (c + 1 < nchunks && c == 0)
+#else
       if (c + 1 < nchunks)
-        b16_chunk_issue<CHUNK_OT * KMAX * 2>(wsrc + (size_t)(c + 1) * ch_v8, lds + (buf ^ 1) * B16_BUF_V8, ch_v8);
-      const v8bf* w0 = lds + buf * B16_BUF_V8 + lane;      // out tile 2c:   [kb][hi|lo][64]
-      const v8bf* w1 = w0 + KB * 2 * 64;                   // out tile 2c+1
-      const int o0 = 2 * c;
-      const int o1 = (2 * c + 1 < MT) ? 2 * c + 1 : 0;
-      const bool two = (2 * c + 1 < MT) && (2 * c + 1 < OT);
-      v4f c0 = acc[o0], c1 = acc[o1];
-      if (two) {
-        v8bf a0h = w0[0], a0l = w0[64], a1h = w1[0], a1l = w1[64];
+#endif
+        b16_chunk_issue<B16_CHUNK_OT * KMAX * 2>(wsrc + (size_t)(c + 1) * ch_v8, lds + (buf ^ 1) * B16_BUF_V8, ch_v8);
+      const v8bf* w = lds + buf * B16_BUF_V8 + lane;      // [ot in chunk][kb][hi|lo][64]
+      if constexpr (DYN) {
 #pragma unroll
-        for (int kb = 0; kb < KMAX; ++kb) {
-          if (!DYN || kb < KB) {
-            v8bf n0h = a0h, n0l = a0l, n1h = a1h, n1l = a1l;
-            if (kb + 1 < KMAX && (!DYN || kb + 1 < KB)) {
-              n0h = w0[(kb + 1) * 128]; n0l = w0[(kb + 1) * 128 + 64];
-              n1h = w1[(kb + 1) * 128]; n1l = w1[(kb + 1) * 128 + 64];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0h, act.hi[kb], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1h, act.hi[kb], c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0h, act.lo[kb], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1h, act.lo[kb], c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0l, act.hi[kb], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1l, act.hi[kb], c1, 0, 0, 0);
-            a0h = n0h; a0l = n0l; a1h = n1h; a1l = n1l;
+        for (int o = 0; o < B16_CHUNK_OT; ++o) {
+          const int ot = B16_CHUNK_OT * c + o;
+          if (ot < MT && ot < OT) {
+            const int oi = (ot < MT) ? ot : 0;
+            acc[oi] = b16_tile_dyn(acc[oi], w + o * KB * 128, act, KB);
+            epi(oi, acc[oi]);
           }
         }
       } else {
+        // the chunk as one flat (out tile, k block) sequence with the fragments of step i+2 in flight;
+        // the pack pads every chunk to B16_CHUNK_OT tiles, so the look-ahead never leaves the buffer
+        const int n_o = OT - B16_CHUNK_OT * c;
+        v8bf fh[3], fl[3];
+        fh[0] = w[0];   fl[0] = w[64];
+        fh[1] = w[128]; fl[1] = w[192];
 #pragma unroll
-        for (int kb = 0; kb < KMAX; ++kb) {
-          if (!DYN || kb < KB) {
-            const v8bf ah = w0[kb * 128], al = w0[kb * 128 + 64];
-            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, act.hi[kb], c0, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, act.lo[kb], c0, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, act.hi[kb], c0, 0, 0, 0);
+        for (int o = 0; o < B16_CHUNK_OT; ++o) {
+          const int ot = B16_CHUNK_OT * c + o;
+          if (ot < MT && o < n_o) {
+            const int oi = (ot < MT) ? ot : 0;
+            v4f cc = acc[oi];
+#pragma unroll
+            for (int kb = 0; kb < KB_T; ++kb) {
+              const int i = o * KB_T + kb;
+              if (i + 2 < B16_CHUNK_OT * KB_T) {
+                fh[(i + 2) % 3] = w[(i + 2) * 128];
+                fl[(i + 2) % 3] = w[(i + 2) * 128 + 64];
+              }
+              __builtin_amdgcn_sched_barrier(0);
+#if B16_EXP == 2
+              cc[0] += (float)fh[i % 3][0] * (float)act.hi[kb][0] + (float)fl[i % 3][1] * (float)act.lo[kb][0];
+#else
+              cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[i % 3], act.hi[kb], cc, 0, 0, 0);
+              cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[i % 3], act.lo[kb], cc, 0, 0, 0);
+              cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl[i % 3], act.hi[kb], cc, 0, 0, 0);
+#endif
+            }
+            epi(oi, cc);
+            acc[oi] = cc;
           }
         }
       }
-      acc[o0] = c0;
-      if (two) acc[o1] = c1;
       __syncthreads();
     }
   }
 }
 
+template <class Epi>
 __device__ __forceinline__ void gemm_b16_dispatch(const int kbp, v4f (&acc)[MT], const B16Act& act, const int OT,
-                                                  const v8bf* __restrict__ wsrc, v8bf* lds) {
+                                                  const v8bf* __restrict__ wsrc, v8bf* lds, const Epi& epi) {
   switch (kbp) {
-    case 8: gemm_b16<8>(acc, act, OT, 8, wsrc, lds); break;
-    case 9: gemm_b16<9>(acc, act, OT, 9, wsrc, lds); break;
-    default: gemm_b16<0>(acc, act, OT, kbp, wsrc, lds); break;
+    case 8: gemm_b16<8>(acc, act, OT, 8, wsrc, lds, epi); break;
+    case 9: gemm_b16<9>(acc, act, OT, 9, wsrc, lds, epi); break;
+    default: gemm_b16<0>(acc, act, OT, kbp, wsrc, lds, epi); break;
   }
 }

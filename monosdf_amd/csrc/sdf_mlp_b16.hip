@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(256) msdf_pack_b16_kernel(const msdf_plan_t pl
     const int n_kt = which == 0 ? L.kt : L.ot;          // k tiles (true count)
     const int kbp = which == 0 ? L.ktp : L.otp;         // k blocks in the pack
     const int off = which == 0 ? L.wf_off : L.wb_off;
-    const int rt_even = (n_rt + 1) & ~1;
+    const int rt_even = (n_rt + B16_CHUNK_OT - 1) / B16_CHUNK_OT * B16_CHUNK_OT;
     const int total = rt_even * kbp * 64;
     for (int i = t0; i < total; i += stride) {
       const int lane = i & 63;
@@ -74,7 +74,7 @@ struct PointCtxB {
 __device__ __forceinline__ PointCtxB load_point_b(const float* __restrict__ x, const int P) {
   PointCtxB c;
   const int lane = lane_id();
-  c.pt = blockIdx.x * MLP_PTS_PER_WG + (threadIdx.x >> 6) * MLP_PTS_PER_WAVE + (lane & 15);
+  c.pt = blockIdx.x * B16_PTS_PER_WG + (threadIdx.x >> 6) * MLP_PTS_PER_WAVE + (lane & 15);
   c.valid = c.pt < P;
   c.ptc = c.valid ? c.pt : (P - 1);
   c.q = lane >> 4;
@@ -97,45 +97,44 @@ __device__ __forceinline__ void input_tiles_b(v4f (&in0)[5], const msdf_plan_t& 
 }
 
 // F (bf16x3): forward only, sdf only
-__global__ void __launch_bounds__(MLP_THREADS, 2)
+__global__ void __launch_bounds__(B16_THREADS, 2)
 msdf_sdf_forward_b16_k(const msdf_plan_t plan, const v8bf* __restrict__ wpack, const float* __restrict__ bpack,
                        const float* __restrict__ x, const float* __restrict__ aux, const int P,
                        const float clamp_radius, const float sphere_scale, float* __restrict__ sdf_out) {
   extern __shared__ v8bf lds16[];
   const PointCtxB c = load_point_b(x, P);
-  v4f h[MT], acc[MT];
+  v4f tl[MT];     // input tiles of the current layer, then (in place) its accumulators / activations
   const int in0_tiles = plan.e_tiles + plan.aux_tiles;
   {
     v4f in0[5];
     input_tiles_b(in0, plan, aux, c);
-    place_tiles(h, 0, in0, in0_tiles);
+    place_tiles(tl, 0, in0, in0_tiles);
   }
   B16Act act;
   const int nl = plan.n_layers;
+  const auto activate = [](const int, v4f& v) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#if B16_EXP == 1
+      v[r] = fmaxf(v[r], 0.f);
+#else
+      float hv, s;
+      softplus100(v[r], hv, s);
+      v[r] = hv;
+#endif
+    }
+  };
   for (int l = 0; l < nl - 1; ++l) {
     const msdf_layer_t L = plan.layer[l];
     if (L.skip_tile >= 0) {
       v4f in0[5];
       input_tiles_b(in0, plan, aux, c);
-      place_tiles(h, L.skip_tile, in0, in0_tiles);
+      place_tiles(tl, L.skip_tile, in0, in0_tiles);
     }
-    b16_from_tiles(act, h, L.kt);
+    b16_from_tiles(act, tl, L.kt);
 #pragma unroll
-    for (int t = 0; t < MT; ++t) acc[t] = (t < L.ot) ? *(const v4f*)(bpack + L.bias_off + 16 * t + 4 * c.q) : V4ZERO;
-    gemm_b16_dispatch(L.ktp, acc, act, L.ot, wpack + L.wf_off, lds16);
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-      v4f v = V4ZERO;
-      if (t < L.ot) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float hv, s;
-          softplus100(acc[t][r], hv, s);
-          v[r] = hv;
-        }
-      }
-      h[t] = v;
-    }
+    for (int t = 0; t < MT; ++t) tl[t] = (t < L.ot) ? *(const v4f*)(bpack + L.bias_off + 16 * t + 4 * c.q) : V4ZERO;
+    gemm_b16_dispatch(L.ktp, tl, act, L.ot, wpack + L.wf_off, lds16, activate);
   }
   // sdf row of the output layer: fp32 dot product on the last hidden activation
   const msdf_layer_t LL = plan.layer[nl - 1];
@@ -144,7 +143,7 @@ msdf_sdf_forward_b16_k(const msdf_plan_t plan, const v8bf* __restrict__ wpack, c
   for (int t = 0; t < MT; ++t) {
     if (t < LL.kt) {
       const v4f w = *(const v4f*)(bpack + plan.wsdf_off + 16 * t + 4 * c.q);
-      part += w.x * h[t].x + w.y * h[t].y + w.z * h[t].z + w.w * h[t].w;
+      part += w.x * tl[t].x + w.y * tl[t].y + w.z * tl[t].z + w.w * tl[t].w;
     }
   }
   float sdf = sum_over_quarters(part) + bpack[LL.bias_off + plan.sdf_slot];
@@ -174,8 +173,8 @@ extern "C" int msdf_sdf_forward_b16(const msdf_plan_t* plan, const void* wpack, 
   if (hipFuncSetAttribute((const void*)msdf_sdf_forward_b16_k, hipFuncAttributeMaxDynamicSharedMemorySize,
                           B16_LDS_BYTES) != hipSuccess)
     return MSDF_ERR_LAUNCH;
-  const int grid = (P + MLP_PTS_PER_WG - 1) / MLP_PTS_PER_WG;
-  msdf_sdf_forward_b16_k<<<grid, MLP_THREADS, B16_LDS_BYTES, (hipStream_t)stream>>>(
+  const int grid = (P + B16_PTS_PER_WG - 1) / B16_PTS_PER_WG;
+  msdf_sdf_forward_b16_k<<<grid, B16_THREADS, B16_LDS_BYTES, (hipStream_t)stream>>>(
       *plan, (const v8bf*)wpack, bpack, x, aux, P, clamp_radius, sphere_scale, sdf);
   return msdf_check_launch();
 }

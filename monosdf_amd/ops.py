@@ -55,7 +55,7 @@ class FusedMlp:
             mp.build_b16()
         flat_w = _need_cuda(flat_w.detach(), 'weights')
         flat_b = _need_cuda(flat_b.detach(), 'biases')
-        wpack = torch.empty(mp.wpack16_v8 * 4 + 4 * 9 * 2 * 64 * 4, device=self.device, dtype=torch.float32)
+        wpack = torch.empty(mp.wpack16_v8 * 4 + 8 * 9 * 2 * 64 * 4, device=self.device, dtype=torch.float32)
         bpack = torch.empty(mp.bpack_f + 64, device=self.device, dtype=torch.float32)
         _lib.call('msdf_pack_weights_b16', C.byref(mp.plan16), _lib.ptr(self.rules_dev), _lib.ptr(self.maps_dev),
                   _lib.ptr(flat_w), _lib.ptr(flat_b), _lib.ptr(wpack), _lib.ptr(bpack), _lib.stream_ptr())

@@ -95,9 +95,9 @@ class MlpPlan:
             L = p16.layer[u]
             L.ktp, L.otp = (L.kt + 1) // 2, (L.ot + 1) // 2
             L.wf_off = off
-            off += _even(L.ot) * L.ktp * 2 * 64
+            off += (L.ot + 3) // 4 * 4 * L.ktp * 2 * 64      # out tiles padded to the 4-tile LDS chunk
             L.wb_off = off
-            off += _even(L.kt) * L.otp * 2 * 64
+            off += (L.kt + 3) // 4 * 4 * L.otp * 2 * 64
         self.plan16 = p16
         self.wpack16_v8 = off
         return p16
