@@ -38,7 +38,7 @@ extern "C" {
 #define MSDF_ERR_LAUNCH 2
 #define MSDF_ERR_UNSUPPORTED 3
 
-#define MSDF_ABI_VERSION 1
+#define MSDF_ABI_VERSION 2
 int msdf_abi_version(void);
 
 /* ---- hash grid (reference: hashencoder/src/hashencoder.h:13-15) ---- */
@@ -55,9 +55,14 @@ int msdf_hash_encode_second_backward(const float* grad, const float* inputs, con
                                      const float* grad_grad_inputs, float* grad_grad, float* grad2_embeddings,
                                      void* stream);
 
-/* ---- fused MLPs ---- */
+/* ---- fused MLPs ----
+ * Every entry point that takes a plan runs on the matrix core named by plan->precision (monosdf_plan.h):
+ * MSDF_PRECISION_F32 = fp32 MFMA; MSDF_PRECISION_BF16X3 = each product as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi
+ * on the bf16 matrix cores with fp32 accumulation (~1e-5 relative error, measured in tests/).  The two use
+ * different weight packs: `wpack` is opaque, sized by the host (monosdf_amd/plan.py) and produced by
+ * msdf_pack_weights for the same plan. */
 int msdf_pack_weights(const msdf_plan_t* plan, const msdf_packrule_t* rules_dev, const int* maps_dev,
-                      const float* flat_w, const float* flat_b, float* wpack, float* bpack, void* stream);
+                      const float* flat_w, const float* flat_b, void* wpack, float* bpack, void* stream);
 
 /* weight normalisation of every layer of a network in one launch (reference: nn.utils.weight_norm hooks,
  * model/network.py:72-73, 239-240, 381-382).  row_layer_dev[r] = layer index of global row r. */
@@ -76,18 +81,11 @@ int msdf_weightnorm_forward(const msdf_wn_layer_t* layers_dev, const int* row_la
 int msdf_weightnorm_backward(const msdf_wn_layer_t* layers_dev, const int* row_layer_dev, int total_rows,
                              const float* g_flat_w, const float* norms, float* dv_flat, float* dg_rows, void* stream);
 
-int msdf_sdf_forward(const msdf_plan_t* plan, const float* wpack, const float* bpack, const float* x,
+int msdf_sdf_forward(const msdf_plan_t* plan, const void* wpack, const float* bpack, const float* x,
                      const float* aux, int P, float clamp_radius, float sphere_scale, float* sdf, void* stream);
 
-/* bf16x3 variants (a*b ~ a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the bf16 matrix cores, fp32 accumulate):
- * `plan` carries K-block counts in ktp/otp and 16-byte pack offsets (monosdf_amd/plan.py build_b16). */
-int msdf_pack_weights_b16(const msdf_plan_t* plan, const msdf_packrule_t* rules_dev, const int* maps_dev,
-                          const float* flat_w, const float* flat_b, void* wpack, float* bpack, void* stream);
-int msdf_sdf_forward_b16(const msdf_plan_t* plan, const void* wpack, const float* bpack, const float* x,
-                         const float* aux, int P, float clamp_radius, float sphere_scale, float* sdf, void* stream);
-
 typedef struct {
-  const float* wpack;
+  const void* wpack;
   const float* bpack;
   const float* x;          /* [P,3] */
   const float* aux;        /* [P, 16*aux_tiles] or NULL */
@@ -109,7 +107,7 @@ typedef struct {
 int msdf_sdf_fwd_grad(const msdf_plan_t* plan, const msdf_fg_args_t* args, void* stream);
 
 typedef struct {
-  const float* wpack;
+  const void* wpack;
   const float* bpack;
   const float* x;
   int32_t P, P_pad;
@@ -132,7 +130,7 @@ typedef struct {
 int msdf_sdf_backward(const msdf_plan_t* plan, const msdf_bw_args_t* args, void* stream);
 
 typedef struct {
-  const float* wpack;
+  const void* wpack;
   const float* bpack;
   const float* x;          /* [P,3] */
   const float* dirs;       /* [P/spr,3] */
@@ -149,7 +147,7 @@ typedef struct {
 int msdf_color_forward(const msdf_plan_t* plan, const msdf_color_fwd_args_t* args, void* stream);
 
 typedef struct {
-  const float* wpack;
+  const void* wpack;
   const float* bpack;
   const float* rgb;
   const float* g_rgb;

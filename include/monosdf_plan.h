@@ -13,6 +13,9 @@
 #define MSDF_MAX_TILES 17  /* 17 * 16 = 272 slots: 256 hidden + one spare tile */
 #define MSDF_MAX_LAYERS 10
 
+#define MSDF_PRECISION_F32 0
+#define MSDF_PRECISION_BF16X3 1
+
 typedef struct {
   int32_t kt;        /* input tiles  (16 slots each) */
   int32_t ot;        /* output tiles */
@@ -42,6 +45,8 @@ typedef struct {
                            < 0: this plan has no sdf row (colour network) */
   int32_t mode;         /* colour network: 1 = idr input [x, PE(v), n, feat], 0 = nerf [PE(v), feat]; sdf: unused */
   int32_t out_act;      /* colour network: 0 sigmoid, 1 relu (if_hdr) */
+  int32_t precision;    /* MSDF_PRECISION_*: which matrix core the kernels run this plan on.  BF16X3 plans count
+                           K in blocks of 32 slots (ktp / otp) and their wf_off / wb_off address bf16 hi/lo packs */
   msdf_layer_t layer[MSDF_MAX_LAYERS];
 } msdf_plan_t;
 

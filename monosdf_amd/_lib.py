@@ -23,7 +23,7 @@ class Layer(C.Structure):
 class Plan(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ('n_layers', 'e_tiles', 'aux_tiles', 'n_freqs', 'sdf_slot', 'feat_tiles', 'hsum',
-                 'qsum', 'absum', 'wsdf_off', 'mode', 'out_act')] + [('layer', Layer * MAX_LAYERS)]
+                 'qsum', 'absum', 'wsdf_off', 'mode', 'out_act', 'precision')] + [('layer', Layer * MAX_LAYERS)]
 
 
 class PackRule(C.Structure):
@@ -133,8 +133,6 @@ _SIGNATURES = {
     'msdf_weightnorm_backward': [_P, _P, C.c_int, _P, _P, _P, _P, _P],
     'msdf_pack_weights': [C.POINTER(Plan), _P, _P, _P, _P, _P, _P, _P],
     'msdf_sdf_forward': [C.POINTER(Plan), _P, _P, _P, _P, C.c_int, C.c_float, C.c_float, _P, _P],
-    'msdf_pack_weights_b16': [C.POINTER(Plan), _P, _P, _P, _P, _P, _P, _P],
-    'msdf_sdf_forward_b16': [C.POINTER(Plan), _P, _P, _P, _P, C.c_int, C.c_float, C.c_float, _P, _P],
     'msdf_sdf_fwd_grad': [C.POINTER(Plan), C.POINTER(FgArgs), _P],
     'msdf_sdf_backward': [C.POINTER(Plan), C.POINTER(BwArgs), _P],
     'msdf_color_forward': [C.POINTER(Plan), C.POINTER(ColorFwdArgs), _P],
@@ -167,7 +165,7 @@ def load():
         fn = getattr(lib, name)        # AttributeError if the symbol is missing: intended
         fn.argtypes = argtypes
         fn.restype = C.c_int
-    if lib.msdf_abi_version() != 1:
+    if lib.msdf_abi_version() != 2:
         raise RuntimeError('monosdf_amd: ABI version mismatch, rebuild the library')
     _lib = lib
     return lib

@@ -335,3 +335,29 @@ __device__ __forceinline__ void pe_jacobian(v4f (&rbar)[5], const float x0, cons
     }
   }
 }
+
+
+// ---------------------------------------------------------------------------
+// The matrix core as the kernel bodies see it (sdf_kernels.h / color_kernels.h are templated on this).
+// gemm(): acc[0..OT) += W * in, then epi(t, acc[t]) for every produced tile.
+// ---------------------------------------------------------------------------
+struct NoEpilogue {
+  __device__ __forceinline__ void operator()(const int, v4f&) const {}
+};
+
+struct CoreF32 {
+  typedef v4f wvec;                                  // one 16-byte element of the weight pack
+  static __device__ __forceinline__ float softplus(const float a) {
+    float h, s;
+    softplus100(a, h, s);
+    return h;
+  }
+  template <class Epi>
+  static __device__ __forceinline__ void gemm(const int kp, v4f (&acc)[MT], const v4f (&in)[MT], const int OT,
+                                              const wvec* __restrict__ wsrc, void* lds, const Epi& epi) {
+    gemm_dispatch(kp, acc, in, OT, wsrc, (v4f*)lds);
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+      if (t < OT) epi(t, acc[t]);
+  }
+};

@@ -17,17 +17,31 @@
 #define B16_EXP 0   // tuning experiments only (scripts/bench_b16.py); 0 = product code
 #endif
 
+
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) v8bf lds_v8bf;
+
+// softplus(beta=100) for the bf16x3 kernels: 2 transcendental + 4 plain VALU instructions per value.
+// Against softplus100() it drops the two selects (threshold 20: difference < 2.1e-11; log1p series for
+// e < 1e-4: absolute difference < 6e-10 on values whose bf16x3 products carry ~1e-5 relative error).
+__device__ __forceinline__ float softplus100_lean(const float a) {
+  const float e = __builtin_amdgcn_exp2f(-fabsf(a * 144.26950408889634f));
+  // max(a, 0) as one integer max on the bit pattern (fmaxf would add a canonicalising v_max(a, a); inline
+  // asm is not an option: the hazard recogniser does not pad MFMA -> inline-asm reads)
+  const float relu = __int_as_float(max(__float_as_int(a), 0));
+  return fmaf(0.006931471805599453f, __builtin_amdgcn_logf(1.0f + e), relu);
+}
 
 #define KB_MAX ((MT + 1) / 2)                       // 9 k-blocks of 32 slots
-// The bf16 matrix cores consume weights 5.3x faster than the fp32 ones, so the L2 -> LDS weight stream,
-// not the MFMA pipe, sizes the workgroup: 8 waves (128 points) share every chunk, one workgroup per CU,
-// 4 out tiles per chunk (72 KB per buffer, double buffered).
-#define B16_WAVES 8
+// Same workgroup shape as the fp32 core: 4 waves x 16 points, two workgroups per CU (72 KB of LDS each), so
+// that one workgroup's load/store-heavy epilogue overlaps the other's matrix products.  (8 waves sharing
+// 4-tile chunks -- half the L2 -> LDS traffic -- measured the same on the forward kernel: the weight
+// stream is not what bounds it, see DESIGN.md.)
+#define B16_WAVES 4
 #define B16_THREADS (64 * B16_WAVES)
 #define B16_PTS_PER_WG (16 * B16_WAVES)
-#define B16_CHUNK_OT 4
-#define B16_BUF_V8 (B16_CHUNK_OT * KB_MAX * 2 * 64) // v8bf (16 B) per LDS buffer: 72 KB
+#define B16_CHUNK_OT 2
+#define B16_BUF_V8 (B16_CHUNK_OT * KB_MAX * 2 * 64) // v8bf (16 B) per LDS buffer: 36 KB
 #define B16_LDS_BYTES (2 * B16_BUF_V8 * 16)
 
 struct B16Act {           // an activation vector as MFMA B operands
@@ -47,12 +61,13 @@ __device__ __forceinline__ void b16_split2(const v4f t0, const v4f t1, v8bf& hi,
   }
 }
 
-// tiles [0, kt) of `t` -> K blocks (zero padding beyond kt)
-__device__ __forceinline__ void b16_from_tiles(B16Act& a, const v4f (&t)[MT], const int kt) {
+// all MT tiles of `t` -> K blocks.  Tiles past a layer's input width must hold finite values (the kernels
+// keep them at zero): their weights are zero in the pack, so they contribute nothing.
+__device__ __forceinline__ void b16_from_tiles(B16Act& a, const v4f (&t)[MT]) {
 #pragma unroll
   for (int kb = 0; kb < KB_MAX; ++kb) {
-    const v4f t0 = (2 * kb < kt) ? t[2 * kb] : V4ZERO;
-    const v4f t1 = (2 * kb + 1 < MT && 2 * kb + 1 < kt) ? t[(2 * kb + 1 < MT) ? 2 * kb + 1 : 0] : V4ZERO;
+    const v4f t0 = t[2 * kb];
+    const v4f t1 = (2 * kb + 1 < MT) ? t[(2 * kb + 1 < MT) ? 2 * kb + 1 : 0] : V4ZERO;
     b16_split2(t0, t1, a.hi[kb], a.lo[kb]);
   }
 }
@@ -71,10 +86,6 @@ __device__ __forceinline__ void b16_chunk_issue(const v8bf* __restrict__ src, v8
     }
   }
 }
-
-struct B16NoEpilogue {
-  __device__ __forceinline__ void operator()(const int, v4f&) const {}
-};
 
 // one out tile against all K blocks (runtime K-block count): c += W[ot] * act (3 MFMAs per K block)
 __device__ __forceinline__ v4f b16_tile_dyn(v4f c, const v8bf* __restrict__ w, const B16Act& act, const int KB) {
@@ -124,6 +135,13 @@ __device__ __forceinline__ void gemm_b16(v4f (&acc)[MT], const B16Act& act, cons
 #endif
         b16_chunk_issue<B16_CHUNK_OT * KMAX * 2>(wsrc + (size_t)(c + 1) * ch_v8, lds + (buf ^ 1) * B16_BUF_V8, ch_v8);
       const v8bf* w = lds + buf * B16_BUF_V8 + lane;      // [ot in chunk][kb][hi|lo][64]
+      // LDS base of this chunk as an opaque 32-bit register: every fragment read below then carries its
+      // offset in the instruction's 16-bit immediate instead of a v_add per read (VALU issue slots are
+      // what this kernel runs out of: a 16x16x32 MFMA blocks the SIMD's vector issue for 8 of its 16 cycles)
+      const lds_v8bf* wl0 = (const lds_v8bf*)w;
+      asm volatile("" : "+v"(wl0));
+      static_assert(B16_BUF_V8 * 16 <= 65536, "fragment offsets must fit the ds_read immediate");
+#define B16_FRAG(i, half) (wl0[(i) * 128 + (half) * 64])
       if constexpr (DYN) {
 #pragma unroll
         for (int o = 0; o < B16_CHUNK_OT; ++o) {
@@ -139,8 +157,8 @@ __device__ __forceinline__ void gemm_b16(v4f (&acc)[MT], const B16Act& act, cons
         // the pack pads every chunk to B16_CHUNK_OT tiles, so the look-ahead never leaves the buffer
         const int n_o = OT - B16_CHUNK_OT * c;
         v8bf fh[3], fl[3];
-        fh[0] = w[0];   fl[0] = w[64];
-        fh[1] = w[128]; fl[1] = w[192];
+        fh[0] = B16_FRAG(0, 0); fl[0] = B16_FRAG(0, 1);
+        fh[1] = B16_FRAG(1, 0); fl[1] = B16_FRAG(1, 1);
 #pragma unroll
         for (int o = 0; o < B16_CHUNK_OT; ++o) {
           const int ot = B16_CHUNK_OT * c + o;
@@ -151,8 +169,8 @@ __device__ __forceinline__ void gemm_b16(v4f (&acc)[MT], const B16Act& act, cons
             for (int kb = 0; kb < KB_T; ++kb) {
               const int i = o * KB_T + kb;
               if (i + 2 < B16_CHUNK_OT * KB_T) {
-                fh[(i + 2) % 3] = w[(i + 2) * 128];
-                fl[(i + 2) % 3] = w[(i + 2) * 128 + 64];
+                fh[(i + 2) % 3] = B16_FRAG(i + 2, 0);
+                fl[(i + 2) % 3] = B16_FRAG(i + 2, 1);
               }
               __builtin_amdgcn_sched_barrier(0);
 #if B16_EXP == 2
@@ -168,6 +186,7 @@ __device__ __forceinline__ void gemm_b16(v4f (&acc)[MT], const B16Act& act, cons
           }
         }
       }
+#undef B16_FRAG
       __syncthreads();
     }
   }
@@ -182,3 +201,16 @@ __device__ __forceinline__ void gemm_b16_dispatch(const int kbp, v4f (&acc)[MT],
     default: gemm_b16<0>(acc, act, OT, kbp, wsrc, lds, epi); break;
   }
 }
+
+struct CoreB16 {
+  typedef v8bf wvec;
+  static __device__ __forceinline__ float softplus(const float a) { return softplus100_lean(a); }
+  // kbp: K blocks (32 slots) of the pack, i.e. ktp / otp of the bf16 plan
+  template <class Epi>
+  static __device__ __forceinline__ void gemm(const int kbp, v4f (&acc)[MT], const v4f (&in)[MT], const int OT,
+                                              const wvec* __restrict__ wsrc, void* lds, const Epi& epi) {
+    B16Act act;
+    b16_from_tiles(act, in);
+    gemm_b16_dispatch(kbp, acc, act, OT, wsrc, (v8bf*)lds, epi);
+  }
+};

@@ -5,7 +5,7 @@
 // ImplicitNetwork / ImplicitNetworkGrid (code/model/network.py:79-137, 247-309)
 // and its autograd double backward (create_graph=True at network.py:125,285,301).
 // Math: DESIGN.md "SDF network kernels".
-#include "mlp_core.h"
+#include "sdf_kernels.h"
 
 // ---------------------------------------------------------------------------
 // weight packer: flat effective weights -> fragment-ordered packs (both orientations)
@@ -76,432 +76,57 @@ __global__ void __launch_bounds__(256) msdf_pack_kernel(const msdf_plan_t plan,
   }
 }
 
-// ---------------------------------------------------------------------------
-// shared pieces
-// ---------------------------------------------------------------------------
-struct PointCtx {
-  int pt;        // global point index of this lane's point (may be >= P on the padded tail)
-  int ptc;       // clamped to P-1 for loads
-  bool valid;
-  int q;         // quarter
-  float x0, x1, x2;
-};
-
-__device__ __forceinline__ PointCtx load_point(const float* __restrict__ x, const int P) {
-  PointCtx c;
-  const int lane = lane_id();
-  const int wave = threadIdx.x >> 6;
-  c.pt = blockIdx.x * MLP_PTS_PER_WG + wave * MLP_PTS_PER_WAVE + (lane & 15);
-  c.valid = c.pt < P;
-  c.ptc = c.valid ? c.pt : (P - 1);
-  c.q = lane >> 4;
-  c.x0 = x[(size_t)c.ptc * 3 + 0];
-  c.x1 = x[(size_t)c.ptc * 3 + 1];
-  c.x2 = x[(size_t)c.ptc * 3 + 2];
-  return c;
-}
-
-// network input tiles: PE tiles then aux tiles (hash-grid features, [P x 16*aux_tiles] row-major)
-__device__ __forceinline__ void load_input_tiles(v4f (&in0)[5], const msdf_plan_t& plan,
-                                                 const float* __restrict__ aux, const PointCtx& c) {
-  pe_values(in0, c.x0, c.x1, c.x2, plan.n_freqs);
-  in0[3] = in0[4] = V4ZERO;
-  if (plan.aux_tiles > 0) {
-    const int aw = 16 * plan.aux_tiles;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-      if (t < plan.aux_tiles) in0[3 + t] = *(const v4f*)(aux + (size_t)c.ptc * aw + 16 * t + 4 * c.q);
-  }
-}
-
-__device__ __forceinline__ void load_bias(v4f (&acc)[MT], const float* __restrict__ b, const int ot, const int q) {
-#pragma unroll
-  for (int t = 0; t < MT; ++t) acc[t] = (t < ot) ? *(const v4f*)(b + 16 * t + 4 * q) : V4ZERO;
-}
-
-// sdf row of the output layer as a dot product over the last hidden activation
-__device__ __forceinline__ float sdf_row_dot(const v4f (&in)[MT], const msdf_plan_t& plan,
-                                             const float* __restrict__ bpack, const int q) {
-  const msdf_layer_t LL = plan.layer[plan.n_layers - 1];
-  float part = 0.f;
-#pragma unroll
-  for (int t = 0; t < MT; ++t) {
-    if (t < LL.kt) {
-      const v4f w = *(const v4f*)(bpack + plan.wsdf_off + 16 * t + 4 * q);
-      part += w.x * in[t].x + w.y * in[t].y + w.z * in[t].z + w.w * in[t].w;
-    }
-  }
-  return sum_over_quarters(part) + bpack[LL.bias_off + plan.sdf_slot];
-}
-
-// ---------------------------------------------------------------------------
-// F: forward only, sdf only (get_sdf_vals; reference network.py:131-137 / 307-309)
-// ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(MLP_THREADS, 2)
 msdf_sdf_forward_k(const msdf_plan_t plan, const v4f* __restrict__ wpack, const float* __restrict__ bpack,
-                        const float* __restrict__ x, const float* __restrict__ aux, const int P,
-                        const float clamp_radius, const float sphere_scale, float* __restrict__ sdf_out) {
+                   const float* __restrict__ x, const float* __restrict__ aux, const int P,
+                   const float clamp_radius, const float sphere_scale, float* __restrict__ sdf_out) {
   extern __shared__ v4f lds[];
-  const PointCtx c = load_point(x, P);
-  v4f in[MT], acc[MT];
-  const int in0_tiles = plan.e_tiles + plan.aux_tiles;
-  {
-    v4f in0[5];
-    load_input_tiles(in0, plan, aux, c);
-    place_tiles(in, 0, in0, in0_tiles);
-  }
-  const int nl = plan.n_layers;
-  for (int l = 0; l < nl - 1; ++l) {
-    const msdf_layer_t L = plan.layer[l];
-    // skip layer: the network input is appended after the hidden tiles (1/sqrt2 folded into the pack)
-    if (L.skip_tile >= 0) {
-      v4f in0[5];
-      load_input_tiles(in0, plan, aux, c);
-      place_tiles(in, L.skip_tile, in0, in0_tiles);
-    }
-    load_bias(acc, bpack + L.bias_off, L.ot, c.q);
-    gemm_dispatch(L.ktp, acc, in, L.ot, wpack + L.wf_off, lds);
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-      v4f h = V4ZERO;
-      if (t < L.ot) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float hv, s;
-          softplus100(acc[t][r], hv, s);
-          h[r] = hv;
-        }
-      }
-      in[t] = h;
-    }
-  }
-  float sdf = sdf_row_dot(in, plan, bpack, c.q);
-  if (clamp_radius > 0.f) {
-    const float nx = sqrtf(c.x0 * c.x0 + c.x1 * c.x1 + c.x2 * c.x2);
-    sdf = fminf(sdf, sphere_scale * (clamp_radius - nx));
-  }
-  if (c.valid && c.q == 0) sdf_out[c.pt] = sdf;
+  sdf_forward_body<CoreF32>(plan, wpack, bpack, x, aux, P, clamp_radius, sphere_scale, sdf_out, lds);
 }
-
-// ---------------------------------------------------------------------------
-// FG: forward + gradient sweep.  Saves H (post-activations) and PM (p_l = s_l * dsdf/dh_{l+1})
-// into the workspace for the backward, and the input block IN0 = [PE | aux] for the weight-gradient GEMM.
-// ---------------------------------------------------------------------------
-typedef msdf_fg_args_t FgArgs;
 
 __global__ void __launch_bounds__(MLP_THREADS, 2)
 msdf_sdf_fwd_grad_k(const msdf_plan_t plan, const FgArgs a) {
   extern __shared__ v4f lds[];
-  const PointCtx c = load_point(a.x, a.P);
-  v4f in[MT], acc[MT];
-  const int nl = plan.n_layers;
-  const int in0_tiles = plan.e_tiles + plan.aux_tiles;
-  const size_t Pp = (size_t)a.P_pad;
-  {
-    v4f in0[5];
-    load_input_tiles(in0, plan, a.aux, c);
-    place_tiles(in, 0, in0, in0_tiles);
-    if (a.save) {
-#pragma unroll
-      for (int t = 0; t < 5; ++t)
-        if (t < in0_tiles) *(v4f*)(a.IN0 + (size_t)c.pt * (16 * in0_tiles) + 16 * t + 4 * c.q) = in0[t];
-    }
-  }
-  // workgroup-uniform on purpose: the gemm below contains barriers and cooperative weight staging
-  const bool want_feat = blockIdx.x * MLP_PTS_PER_WG < a.n_feat;
-
-  // ---------------- forward chain ----------------
-  for (int l = 0; l < nl - 1; ++l) {
-    const msdf_layer_t L = plan.layer[l];
-    if (L.skip_tile >= 0) {
-      v4f in0[5];
-      load_input_tiles(in0, plan, a.aux, c);
-      place_tiles(in, L.skip_tile, in0, in0_tiles);
-    }
-    load_bias(acc, a.bpack + L.bias_off, L.ot, c.q);
-    gemm_dispatch(L.ktp, acc, in, L.ot, (const v4f*)a.wpack + L.wf_off, lds);
-    float* Hl = a.H + (size_t)L.hpre * Pp + (size_t)c.pt * (16 * L.ot) + 4 * c.q;
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-      v4f h = V4ZERO;
-      if (t < L.ot) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float hv, s;
-          softplus100(acc[t][r], hv, s);
-          h[r] = hv;
-        }
-        *(v4f*)(Hl + 16 * t) = h;
-      }
-      in[t] = h;
-    }
-  }
-  // ---------------- output layer ----------------
-  const msdf_layer_t LL = plan.layer[nl - 1];
-  float sdf;
-  if (want_feat) {
-    load_bias(acc, a.bpack + LL.bias_off, LL.ot, c.q);
-    gemm_dispatch(LL.ktp, acc, in, LL.ot, (const v4f*)a.wpack + LL.wf_off, lds);
-    if (c.valid && c.pt < a.n_feat) {
-      float* f = a.feat + (size_t)c.pt * (16 * plan.feat_tiles) + 4 * c.q;
-#pragma unroll
-      for (int t = 0; t < MT; ++t)
-        if (t < plan.feat_tiles) *(v4f*)(f + 16 * t) = acc[t];
-    }
-    // sdf sits in slot sdf_slot = 16 * feat_tiles (quarter 0, component 0 of that tile)
-    float sv = 0.f;
-#pragma unroll
-    for (int t = 0; t < MT; ++t)
-      if (t == plan.feat_tiles) sv = acc[t].x;
-    sdf = __shfl(sv, lane_id() & 15, 64);
-  } else {
-    sdf = sdf_row_dot(in, plan, a.bpack, c.q);
-  }
-
-  // ---------------- gradient sweep (reverse mode through the sdf row) ----------------
-  // acc carries g = d sdf / d h_{l+1} between iterations
-#pragma unroll
-  for (int t = 0; t < MT; ++t)
-    acc[t] = (t < LL.kt) ? *(const v4f*)(a.bpack + plan.wsdf_off + 16 * t + 4 * c.q) : V4ZERO;
-  v4f r_in[5];
-#pragma unroll
-  for (int t = 0; t < 5; ++t) r_in[t] = V4ZERO;
-  for (int l = nl - 2; l >= 0; --l) {
-    const msdf_layer_t L = plan.layer[l];
-    const float* Hl = a.H + (size_t)L.hpre * Pp + (size_t)c.pt * (16 * L.ot) + 4 * c.q;
-    float* Pl = a.PM + (size_t)L.hpre * Pp + (size_t)c.pt * (16 * L.ot) + 4 * c.q;
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-      v4f p = V4ZERO;
-      if (t < L.ot) {
-        const v4f h = *(const v4f*)(Hl + 16 * t);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) p[r] = (1.0f - one_minus_sigmoid_from_h(h[r])) * acc[t][r];
-        if (a.save) *(v4f*)(Pl + 16 * t) = p;
-      }
-      in[t] = p;
-    }
-    zero_tiles(acc);
-    gemm_dispatch(L.otp, acc, in, L.kt, (const v4f*)a.wpack + L.wb_off, lds);
-    if (l == 0) {
-      gather_tiles(r_in, acc, 0, in0_tiles);
-    } else if (L.skip_tile >= 0) {
-      gather_tiles(r_in, acc, L.skip_tile, in0_tiles);
-#pragma unroll
-      for (int t = 0; t < MT; ++t)
-        if (t >= L.skip_tile) acc[t] = V4ZERO;
-    }
-  }
-  // ---------------- d sdf / d x through the PE, clamp, stores ----------------
-  float n0, n1, n2;
-  pe_jacobian_transpose(r_in, c.x0, c.x1, c.x2, plan.n_freqs, n0, n1, n2);
-  bool is_clamped = false;
-  if (a.clamp_radius > 0.f && c.pt < a.n_clamp) {
-    const float nx = sqrtf(c.x0 * c.x0 + c.x1 * c.x1 + c.x2 * c.x2);
-    const float sph = a.sphere_scale * (a.clamp_radius - nx);
-    if (sph < sdf) {
-      is_clamped = true;
-      sdf = sph;
-      const float inv = -a.sphere_scale / nx;
-      n0 = c.x0 * inv; n1 = c.x1 * inv; n2 = c.x2 * inv;
-    }
-  }
-  if (c.valid) {
-    if (c.q == 0) {
-      a.sdf[c.pt] = sdf;
-      a.nrm[(size_t)c.pt * 3 + 0] = n0;
-      a.nrm[(size_t)c.pt * 3 + 1] = n1;
-      a.nrm[(size_t)c.pt * 3 + 2] = n2;
-      a.clamped[c.pt] = is_clamped ? 1 : 0;
-    }
-    if (a.r_aux != nullptr) {
-      const int aw = 16 * plan.aux_tiles;
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-        if (t < plan.aux_tiles) {
-          v4f v = r_in[3 + t];
-          if (is_clamped) v = V4ZERO;
-          *(v4f*)(a.r_aux + (size_t)c.pt * aw + 16 * t + 4 * c.q) = v;
-        }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// B: double backward.  Given d loss/d sdf, d loss/d feat, d loss/d nrm (and d loss/d r_aux),
-// sweep up (second-order terms) then down (ordinary backward with the extra a-bar terms),
-// leaving the operands of the weight-gradient GEMMs in the workspace:
-//   QB_l = q-bar_l (input side),  PM_l (from FG),  AB_l = a-bar_l,  H_l / IN0 (from FG).
-// ---------------------------------------------------------------------------
-typedef msdf_bw_args_t BwArgs;
-
-__device__ __forceinline__ void load_rbar(v4f (&rbar)[5], const msdf_plan_t& plan, const BwArgs& a,
-                                          const PointCtx& c, const bool live, const float gn0, const float gn1,
-                                          const float gn2) {
-  pe_jacobian(rbar, c.x0, c.x1, c.x2, plan.n_freqs, gn0, gn1, gn2);
-  rbar[3] = rbar[4] = V4ZERO;
-  if (a.g_raux != nullptr && live) {
-    const int aw = 16 * plan.aux_tiles;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-      if (t < plan.aux_tiles) rbar[3 + t] = *(const v4f*)(a.g_raux + (size_t)c.pt * aw + 16 * t + 4 * c.q);
-  }
+  sdf_fwd_grad_body<CoreF32>(plan, a, lds);
 }
 
 __global__ void __launch_bounds__(MLP_THREADS, 2)
 msdf_sdf_backward_k(const msdf_plan_t plan, const BwArgs a) {
   extern __shared__ v4f lds[];
-  const PointCtx c = load_point(a.x, a.P);
-  const int nl = plan.n_layers;
-  const size_t Pp = (size_t)a.P_pad;
-  const bool live = c.valid && !(a.clamped != nullptr && a.clamped[c.ptc]);
-  float gs = 0.f, gn0 = 0.f, gn1 = 0.f, gn2 = 0.f;
-  if (live) {
-    if (a.g_sdf) gs = a.g_sdf[c.pt];
-    if (a.g_nrm) {
-      gn0 = a.g_nrm[(size_t)c.pt * 3 + 0];
-      gn1 = a.g_nrm[(size_t)c.pt * 3 + 1];
-      gn2 = a.g_nrm[(size_t)c.pt * 3 + 2];
-    }
-  }
-  if (c.q == 0) a.GSDF[c.pt] = gs;
-  const int in0_tiles = plan.e_tiles + plan.aux_tiles;
-
-  v4f in[MT], acc[MT];
-  {
-    v4f rbar[5];
-    load_rbar(rbar, plan, a, c, live, gn0, gn1, gn2);
-    place_tiles(in, 0, rbar, in0_tiles);
-  }
-
-  // ---------------- sweep up: p-bar_l = W_l q-bar_l ----------------
-  for (int l = 0; l < nl - 1; ++l) {
-    const msdf_layer_t L = plan.layer[l];
-    if (L.skip_tile >= 0) {
-      v4f rbar[5];
-      load_rbar(rbar, plan, a, c, live, gn0, gn1, gn2);
-      place_tiles(in, L.skip_tile, rbar, in0_tiles);
-    }
-    float* Ql = a.QB + (size_t)L.qpre * Pp + (size_t)c.pt * (16 * L.kt) + 4 * c.q;
-#pragma unroll
-    for (int t = 0; t < MT; ++t)
-      if (t < L.kt) *(v4f*)(Ql + 16 * t) = in[t];
-    zero_tiles(acc);
-    gemm_dispatch(L.ktp, acc, in, L.ot, (const v4f*)a.wpack + L.wf_off, lds);
-    const size_t off = (size_t)L.hpre * Pp + (size_t)c.pt * (16 * L.ot) + 4 * c.q;
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-      v4f qn = V4ZERO;
-      if (t < L.ot) {
-        const v4f h = *(const v4f*)(a.H + off + 16 * t);
-        const v4f p = *(const v4f*)(a.PM + off + 16 * t);
-        v4f tt;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float u = one_minus_sigmoid_from_h(h[r]);
-          const float pb = acc[t][r];
-          tt[r] = 100.0f * u * p[r] * pb;   // s-bar * softplus''  with  p = s q
-          qn[r] = (1.0f - u) * pb;
-        }
-        *(v4f*)(a.T + off + 16 * t) = tt;
-      }
-      in[t] = qn;
-    }
-  }
-  const msdf_layer_t LL = plan.layer[nl - 1];
-  {
-    // q-bar of the last layer's input: d W_last[sdf row] = sum_p q-bar (one row of ones on the X side)
-    float* Ql = a.QLAST + (size_t)c.pt * (16 * LL.kt) + 4 * c.q;
-#pragma unroll
-    for (int t = 0; t < MT; ++t)
-      if (t < LL.kt) *(v4f*)(Ql + 16 * t) = in[t];
-  }
-
-  // ---------------- sweep down ----------------
-  // a-bar of the output layer: feature gradient tiles + the sdf slot
-  const bool has_feat = (a.g_feat != nullptr) && c.valid && c.pt < a.n_feat;
-  {
-    float* ABl = a.AB + (size_t)LL.abpre * Pp + (size_t)c.pt * (16 * LL.ot) + 4 * c.q;
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-      v4f v = V4ZERO;
-      if (t < plan.feat_tiles) {
-        if (has_feat) v = *(const v4f*)(a.g_feat + (size_t)c.pt * (16 * plan.feat_tiles) + 16 * t + 4 * c.q);
-      } else if (t == plan.feat_tiles) {
-        if (c.q == 0) v.x = gs;
-      }
-      if (t < LL.ot) *(v4f*)(ABl + 16 * t) = v;
-      in[t] = v;
-    }
-  }
-  zero_tiles(acc);
-  gemm_dispatch(LL.otp, acc, in, LL.kt, (const v4f*)a.wpack + LL.wb_off, lds);
-  v4f gin0[5];
-#pragma unroll
-  for (int t = 0; t < 5; ++t) gin0[t] = V4ZERO;
-  for (int l = nl - 2; l >= 0; --l) {
-    const msdf_layer_t L = plan.layer[l];
-    const size_t off = (size_t)L.hpre * Pp + (size_t)c.pt * (16 * L.ot) + 4 * c.q;
-    float* ABl = a.AB + (size_t)L.abpre * Pp + (size_t)c.pt * (16 * L.ot) + 4 * c.q;
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-      v4f ab = V4ZERO;
-      if (t < L.ot) {
-        const v4f h = *(const v4f*)(a.H + off + 16 * t);
-        const v4f tt = *(const v4f*)(a.T + off + 16 * t);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ab[r] = acc[t][r] * (1.0f - one_minus_sigmoid_from_h(h[r])) + tt[r];
-        *(v4f*)(ABl + 16 * t) = ab;
-      }
-      in[t] = ab;
-    }
-    if (l == 0 && a.g_aux == nullptr) break;   // d loss / d x is not needed: skip the last product
-    zero_tiles(acc);
-    gemm_dispatch(L.otp, acc, in, L.kt, (const v4f*)a.wpack + L.wb_off, lds);
-    if (a.g_aux != nullptr) {
-      if (l == 0) gather_tiles(gin0, acc, 0, in0_tiles);
-      else if (L.skip_tile >= 0) gather_tiles(gin0, acc, L.skip_tile, in0_tiles);
-    }
-    if (l > 0 && L.skip_tile >= 0) {
-#pragma unroll
-      for (int t = 0; t < MT; ++t)
-        if (t >= L.skip_tile) acc[t] = V4ZERO;
-    }
-  }
-  if (a.g_aux != nullptr && c.valid) {
-    const int aw = 16 * plan.aux_tiles;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-      if (t < plan.aux_tiles) *(v4f*)(a.g_aux + (size_t)c.pt * aw + 16 * t + 4 * c.q) = gin0[3 + t];
-  }
+  sdf_backward_body<CoreF32>(plan, a, lds);
 }
 
-// ---------------------------------------------------------------------------
-// C-ABI
-// ---------------------------------------------------------------------------
-static int mlp_prepare(const void* fn) {
-  return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS_BYTES) == hipSuccess
-             ? MSDF_OK : MSDF_ERR_LAUNCH;
-}
+// bf16x3 launchers (sdf_mlp_b16.hip)
+int msdf_b16_pack_weights(const msdf_plan_t*, const msdf_packrule_t*, const int*, const float*, const float*, void*,
+                          float*, hipStream_t);
+int msdf_b16_sdf_forward(const msdf_plan_t*, const void*, const float*, const float*, const float*, int, float, float,
+                         float*, hipStream_t);
+int msdf_b16_sdf_fwd_grad(const msdf_plan_t*, const msdf_fg_args_t*, hipStream_t);
+int msdf_b16_sdf_backward(const msdf_plan_t*, const msdf_bw_args_t*, hipStream_t);
 
 extern "C" int msdf_abi_version(void) { return MSDF_ABI_VERSION; }
 
 extern "C" int msdf_pack_weights(const msdf_plan_t* plan, const msdf_packrule_t* rules_dev, const int* maps_dev,
-                                 const float* flat_w, const float* flat_b, float* wpack, float* bpack,
+                                 const float* flat_w, const float* flat_b, void* wpack, float* bpack,
                                  void* stream) {
   if (plan == nullptr || plan->n_layers < 1 || plan->n_layers > MSDF_MAX_LAYERS) return MSDF_ERR_ARG;
+  if (plan->precision == MSDF_PRECISION_BF16X3)
+    return msdf_b16_pack_weights(plan, rules_dev, maps_dev, flat_w, flat_b, wpack, bpack, (hipStream_t)stream);
+  if (plan->precision != MSDF_PRECISION_F32) return MSDF_ERR_ARG;
   const dim3 grid(32, plan->n_layers, 3);
   msdf_pack_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(*plan, rules_dev, maps_dev, flat_w, flat_b, (v4f*)wpack,
                                                           bpack);
   return msdf_check_launch();
 }
 
-extern "C" int msdf_sdf_forward(const msdf_plan_t* plan, const float* wpack, const float* bpack, const float* x,
+extern "C" int msdf_sdf_forward(const msdf_plan_t* plan, const void* wpack, const float* bpack, const float* x,
                                 const float* aux, int P, float clamp_radius, float sphere_scale, float* sdf,
                                 void* stream) {
   if (plan == nullptr || P < 0) return MSDF_ERR_ARG;
   if (P == 0) return MSDF_OK;
   if (plan->aux_tiles > 0 && aux == nullptr) return MSDF_ERR_ARG;
+  if (plan->precision == MSDF_PRECISION_BF16X3)
+    return msdf_b16_sdf_forward(plan, wpack, bpack, x, aux, P, clamp_radius, sphere_scale, sdf, (hipStream_t)stream);
   if (mlp_prepare((const void*)msdf_sdf_forward_k)) return MSDF_ERR_LAUNCH;
   const int grid = (P + MLP_PTS_PER_WG - 1) / MLP_PTS_PER_WG;
   msdf_sdf_forward_k<<<grid, MLP_THREADS, MLP_LDS_BYTES, (hipStream_t)stream>>>(
@@ -514,6 +139,7 @@ extern "C" int msdf_sdf_fwd_grad(const msdf_plan_t* plan, const msdf_fg_args_t* 
   if (a->P == 0) return MSDF_OK;
   if (a->P_pad < a->P || (a->P_pad % MLP_PTS_PER_WG) != 0) return MSDF_ERR_ARG;
   if (plan->aux_tiles > 0 && a->aux == nullptr) return MSDF_ERR_ARG;
+  if (plan->precision == MSDF_PRECISION_BF16X3) return msdf_b16_sdf_fwd_grad(plan, a, (hipStream_t)stream);
   if (mlp_prepare((const void*)msdf_sdf_fwd_grad_k)) return MSDF_ERR_LAUNCH;
   msdf_sdf_fwd_grad_k<<<a->P_pad / MLP_PTS_PER_WG, MLP_THREADS, MLP_LDS_BYTES, (hipStream_t)stream>>>(*plan, *a);
   return msdf_check_launch();
@@ -523,6 +149,7 @@ extern "C" int msdf_sdf_backward(const msdf_plan_t* plan, const msdf_bw_args_t* 
   if (plan == nullptr || a == nullptr || a->P < 0) return MSDF_ERR_ARG;
   if (a->P == 0) return MSDF_OK;
   if (a->P_pad < a->P || (a->P_pad % MLP_PTS_PER_WG) != 0) return MSDF_ERR_ARG;
+  if (plan->precision == MSDF_PRECISION_BF16X3) return msdf_b16_sdf_backward(plan, a, (hipStream_t)stream);
   if (mlp_prepare((const void*)msdf_sdf_backward_k)) return MSDF_ERR_LAUNCH;
   msdf_sdf_backward_k<<<a->P_pad / MLP_PTS_PER_WG, MLP_THREADS, MLP_LDS_BYTES, (hipStream_t)stream>>>(*plan, *a);
   return msdf_check_launch();

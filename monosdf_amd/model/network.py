@@ -8,6 +8,8 @@ HIP kernel reached through monosdf_amd.ops (no eager-PyTorch fallback: CPU tenso
 """
 import math
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -57,10 +59,26 @@ class _FusedNet(nn.Module):
     def _layers(self):
         return [getattr(self, 'lin%d' % l) for l in range(self.num_layers - 1)]
 
+    # matrix core of the fused kernels: 'fp32' (default) or 'bf16x3'.  Not a reference option: set it with
+    # set_precision() / MonoSDFNetwork.set_precision() or the MONOSDF_PRECISION environment variable.
+    precision = None
+    supports_bf16x3 = False
+
+    def set_precision(self, precision):
+        if precision not in ops.PRECISIONS:
+            raise ValueError('precision must be one of %s' % (ops.PRECISIONS,))
+        if precision != 'fp32' and not self.supports_bf16x3:
+            precision = 'fp32'
+        object.__setattr__(self, 'precision', precision)
+        object.__setattr__(self, '_fused_state', None)
+
     def _fused(self, device):
         f = getattr(self, '_fused_state', None)
         if f is None or f.device != device:
-            f = ops.FusedMlp(self._build_plan(), device)
+            prec = self.precision or os.environ.get('MONOSDF_PRECISION', 'fp32')
+            if not self.supports_bf16x3:
+                prec = 'fp32'
+            f = ops.FusedMlp(self._build_plan(), device, prec)
             object.__setattr__(self, '_fused_state', f)
         return f
 
@@ -113,6 +131,8 @@ def _geometric_init(l, num_layers, dims, skip_in, multires, bias, inside_outside
 
 class _SdfBase(_FusedNet):
     """Common part of ImplicitNetwork / ImplicitNetworkGrid."""
+
+    supports_bf16x3 = True
 
     def _make_layers(self, dims, geometric_init, bias, skip_in, weight_norm, multires, inside_outside):
         self.num_layers = len(dims)
@@ -319,6 +339,12 @@ class MonoSDFNetwork(nn.Module):
         self.density = LaplaceDensity(**conf.get_config('density'))
         self.ray_sampler = ErrorBoundSampler(self.scene_bounding_sphere, **conf.get_config('ray_sampler'))
         self._noise = None      # tests inject the six random draws here (SURVEY.md 8(a) RNG note)
+
+    def set_precision(self, precision):
+        """'fp32' or 'bf16x3' matrix core for the fused MLP kernels (not a reference option)."""
+        self.implicit_network.set_precision(precision)
+        self.rendering_network.set_precision(precision)
+        return self
 
     def _bg_list(self):
         bg = getattr(self, '_bg_cache', None)

@@ -26,38 +26,64 @@ def _pad64(n):
     return (n + 63) // 64 * 64
 
 
+# matrix core of the fused MLP kernels (include/monosdf_plan.h MSDF_PRECISION_*)
+PRECISIONS = ('fp32', 'bf16x3')
+
+
+# ---------------------------------------------------------------------------
+# side stream: the colour network's weight-gradient GEMM does not feed the SDF backward kernel, and that
+# kernel's last round fills only a fifth of the chip (1632 workgroups on 512 slots) -- so the two overlap.
+# ---------------------------------------------------------------------------
+import os as _os
+
+_SIDE_STREAMS = {}
+_PENDING = []          # events of side-stream work whose results the main stream has not waited for yet
+USE_SIDE_STREAM = _os.environ.get('MSDF_SIDE_STREAM', '1') != '0'
+
+
+def _side_stream(device):
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
+    return _SIDE_STREAMS[key]
+
+
+def join_side_work():
+    """Make the current stream wait for everything queued on the side stream (cheap when there is nothing)."""
+    if _PENDING:
+        cur = torch.cuda.current_stream()
+        for ev in _PENDING:
+            cur.wait_event(ev)
+        _PENDING.clear()
+
+
 class FusedMlp:
     """Device-side state of one fused network (plan, pack rules, maps, caches)."""
 
-    def __init__(self, mlp_plan, device):
+    def __init__(self, mlp_plan, device, precision='fp32'):
+        if precision not in PRECISIONS:
+            raise ValueError('monosdf_amd: precision must be one of %s, got %r' % (PRECISIONS, precision))
         self.mp = mlp_plan
         self.device = device
+        self.precision = precision
+        # the plan the kernels get: same geometry, K counts / pack offsets of the chosen matrix core
+        self.plan = mlp_plan.plan if precision == 'fp32' else mlp_plan.build_b16()
         self.rules_dev = torch.from_numpy(mlp_plan.rules_np).to(device)
         self.maps_dev = torch.from_numpy(mlp_plan.maps_np).to(device)
         self._wgrad_cache = {}
 
     # -- weights -----------------------------------------------------------------
     def pack(self, flat_w, flat_b):
+        """Fragment-ordered weight packs of this network's matrix core (+ one LDS chunk of slack: the
+        kernels stage whole chunks)."""
         mp = self.mp
         flat_w = _need_cuda(flat_w.detach(), 'weights')
         flat_b = _need_cuda(flat_b.detach(), 'biases')
         assert flat_w.numel() == mp.n_w and flat_b.numel() == mp.n_b
-        wpack = torch.empty(mp.wpack_f4 * 4 + 2 * 17 * 64 * 4, device=self.device, dtype=torch.float32)
+        units16 = mp.wpack_f4 if self.precision == 'fp32' else mp.wpack16_v8
+        wpack = torch.empty(units16 * 4 + 4 * 17 * 64 * 4, device=self.device, dtype=torch.float32)
         bpack = torch.empty(mp.bpack_f + 64, device=self.device, dtype=torch.float32)
-        _lib.call('msdf_pack_weights', C.byref(mp.plan), _lib.ptr(self.rules_dev), _lib.ptr(self.maps_dev),
-                  _lib.ptr(flat_w), _lib.ptr(flat_b), _lib.ptr(wpack), _lib.ptr(bpack), _lib.stream_ptr())
-        return wpack, bpack
-
-    def pack_b16(self, flat_w, flat_b):
-        """bf16 hi/lo packs for the bf16x3 kernels."""
-        mp = self.mp
-        if not hasattr(mp, 'plan16'):
-            mp.build_b16()
-        flat_w = _need_cuda(flat_w.detach(), 'weights')
-        flat_b = _need_cuda(flat_b.detach(), 'biases')
-        wpack = torch.empty(mp.wpack16_v8 * 4 + 8 * 9 * 2 * 64 * 4, device=self.device, dtype=torch.float32)
-        bpack = torch.empty(mp.bpack_f + 64, device=self.device, dtype=torch.float32)
-        _lib.call('msdf_pack_weights_b16', C.byref(mp.plan16), _lib.ptr(self.rules_dev), _lib.ptr(self.maps_dev),
+        _lib.call('msdf_pack_weights', C.byref(self.plan), _lib.ptr(self.rules_dev), _lib.ptr(self.maps_dev),
                   _lib.ptr(flat_w), _lib.ptr(flat_b), _lib.ptr(wpack), _lib.ptr(bpack), _lib.stream_ptr())
         return wpack, bpack
 
@@ -148,6 +174,7 @@ class FusedWeightNormFunction(torch.autograd.Function):
         st, layers = ctx.st, ctx.layers
         norms, = ctx.saved_tensors
         dev = norms.device
+        join_side_work()            # g_w may have been produced on the side stream
         g_w = g_w.contiguous()
         dv = torch.empty(st.n_w, device=dev, dtype=torch.float32)
         dg = torch.empty(st.total_rows, device=dev, dtype=torch.float32)
@@ -178,13 +205,12 @@ def fused_weight_norm(state, layers):
 # ---------------------------------------------------------------------------
 # SDF network
 # ---------------------------------------------------------------------------
-def sdf_forward_nograd(mlp, wpack, bpack, x, aux, clamp_radius, sphere_scale, b16=False):
-    """get_sdf_vals: forward only (sampler).  b16: bf16x3 kernel with packs from FusedMlp.pack_b16."""
+def sdf_forward_nograd(mlp, wpack, bpack, x, aux, clamp_radius, sphere_scale):
+    """get_sdf_vals: forward only (sampler)."""
     x = _need_cuda(x, 'points')
     P = x.shape[0]
     out = torch.empty(P, 1, device=x.device, dtype=torch.float32)
-    plan = mlp.mp.plan16 if b16 else mlp.mp.plan
-    _lib.call('msdf_sdf_forward_b16' if b16 else 'msdf_sdf_forward', C.byref(plan), _lib.ptr(wpack), _lib.ptr(bpack),
+    _lib.call('msdf_sdf_forward', C.byref(mlp.plan), _lib.ptr(wpack), _lib.ptr(bpack),
               _lib.ptr(x), _lib.ptr(aux), P, float(clamp_radius), float(sphere_scale), _lib.ptr(out),
               _lib.stream_ptr())
     return out
@@ -197,7 +223,7 @@ class SdfMlpFunction(torch.autograd.Function):
     def forward(ctx, x, aux, flat_w, flat_b, wpack, bpack, mlp, n_clamp, n_feat, clamp_radius,
                 sphere_scale, save):
         mp = mlp.mp
-        plan = mp.plan
+        plan = mlp.plan
         x = _need_cuda(x.detach(), 'points')
         P = x.shape[0]
         P_pad = _pad64(max(P, 1))
@@ -249,7 +275,7 @@ class SdfMlpFunction(torch.autograd.Function):
         x, ws, clamped, wpack, bpack = ctx.saved_tensors
         mlp, P, P_pad = ctx.mlp, ctx.P, ctx.P_pad
         mp = mlp.mp
-        plan = mp.plan
+        plan = mlp.plan
         dev = x.device
         woff, _ = planlib.sdf_workspace(mp, P_pad)
         cont = lambda t: None if t is None else t.contiguous()
@@ -284,7 +310,7 @@ class ColorMlpFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, dirs, nrm, feat, code, flat_w, flat_b, wpack, bpack, cmlp, spr, save):
         mp = cmlp.mp
-        plan = mp.plan
+        plan = cmlp.plan
         x = _need_cuda(x.detach(), 'points')
         dirs = _need_cuda(dirs.detach(), 'view dirs')
         nrm = _need_cuda(nrm.detach(), 'normals')
@@ -329,7 +355,7 @@ class ColorMlpFunction(torch.autograd.Function):
         rgb, feat, ws, wpack, bpack = ctx.saved_tensors
         cmlp, P, P_pad = ctx.cmlp, ctx.P, ctx.P_pad
         mp = cmlp.mp
-        plan = mp.plan
+        plan = cmlp.plan
         dev = rgb.device
         woff, _ = planlib.color_workspace(mp, P_pad)
         g_rgb = g_rgb.contiguous()
@@ -343,7 +369,19 @@ class ColorMlpFunction(torch.autograd.Function):
         b.g_feat, b.g_misc = g_feat.data_ptr(), g_misc.data_ptr()
         if P > 0:
             _lib.call('msdf_color_backward', C.byref(plan), C.byref(b), _lib.stream_ptr())
-            grad = cmlp.run_wgrad(P_pad, {'ws': ws, 'feat': feat})
+            if USE_SIDE_STREAM:
+                main, side = torch.cuda.current_stream(), _side_stream(dev)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    grad = cmlp.run_wgrad(P_pad, {'ws': ws, 'feat': feat})
+                    done = torch.cuda.Event()
+                    done.record(side)
+                for t in (ws, feat):
+                    t.record_stream(side)       # saved tensors are released before the side stream is done
+                grad.record_stream(main)
+                _PENDING.append(done)
+            else:
+                grad = cmlp.run_wgrad(P_pad, {'ws': ws, 'feat': feat})
         else:
             grad = torch.zeros(mp.n_w + mp.n_b, device=dev)
         g_nrm = g_misc[:, mp.lead - 3:mp.lead].contiguous() if plan.mode == 1 else None

@@ -87,9 +87,11 @@ class MlpPlan:
     def build_b16(self):
         """Second plan for the bf16x3 kernels: ktp / otp = K-block counts (32 slots), wf_off / wb_off =
         16-byte offsets of the hi/lo packs; everything else identical."""
-        import copy
+        if getattr(self, 'plan16', None) is not None:
+            return self.plan16
         p16 = _lib.Plan()
         C.memmove(C.byref(p16), C.byref(self.plan), C.sizeof(_lib.Plan))
+        p16.precision = 1            # MSDF_PRECISION_BF16X3
         off = 0
         for u in range(self.plan.n_layers):
             L = p16.layer[u]
