@@ -1,0 +1,185 @@
+// Colour-network kernel bodies, templated on the matrix core (CoreF32 / CoreB16); see color_mlp.hip.
+#pragma once
+#include "mlp_core.h"
+
+typedef msdf_color_fwd_args_t ColorFwdArgs;
+
+__device__ __forceinline__ int wave_point(int& q) {
+  const int lane = lane_id();
+  q = lane >> 4;
+  return blockIdx.x * MLP_PTS_PER_WG + (threadIdx.x >> 6) * MLP_PTS_PER_WAVE + (lane & 15);
+}
+
+// misc block in slot layout: idr: [x(3) | PE(v) | n(3)], nerf: [PE(v)]; then code tiles
+__device__ __forceinline__ void color_misc_tiles(v4f (&m)[5], const msdf_plan_t& plan, const float* __restrict__ x,
+                                                 const float* __restrict__ dirs, const float* __restrict__ nrm,
+                                                 const float* __restrict__ code, const int ptc, const int ray,
+                                                 const int q) {
+  const int nv = 3 + 6 * plan.n_freqs;
+  const float v0 = dirs[(size_t)ray * 3 + 0], v1 = dirs[(size_t)ray * 3 + 1], v2 = dirs[(size_t)ray * 3 + 2];
+  float x0 = 0.f, x1 = 0.f, x2 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
+  if (plan.mode == 1) {
+    x0 = x[(size_t)ptc * 3 + 0]; x1 = x[(size_t)ptc * 3 + 1]; x2 = x[(size_t)ptc * 3 + 2];
+    n0 = nrm[(size_t)ptc * 3 + 0]; n1 = nrm[(size_t)ptc * 3 + 1]; n2 = nrm[(size_t)ptc * 3 + 2];
+  }
+  const int pe0 = (plan.mode == 1) ? 3 : 0;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = 16 * t + 4 * q + r;
+      float val = 0.f;
+      if (j < pe0) {
+        val = (j == 0) ? x0 : (j == 1) ? x1 : x2;
+      } else if (j < pe0 + nv) {
+        float dv; int c;
+        pe_slot(j - pe0, nv, v0, v1, v2, val, dv, c);
+      } else if (plan.mode == 1 && j < pe0 + nv + 3) {
+        const int k = j - pe0 - nv;
+        val = (k == 0) ? n0 : (k == 1) ? n1 : n2;
+      }
+      m[t][r] = val;
+    }
+  }
+  m[3] = m[4] = V4ZERO;
+  if (plan.aux_tiles > 0 && code != nullptr) {
+    const int aw = 16 * plan.aux_tiles;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      if (t < plan.aux_tiles) m[3 + t] = *(const v4f*)(code + (size_t)ray * aw + 16 * t + 4 * q);
+  }
+}
+
+__device__ __forceinline__ void load_bias_c(v4f (&acc)[MT], const float* __restrict__ b, const int ot, const int q) {
+#pragma unroll
+  for (int t = 0; t < MT; ++t) acc[t] = (t < ot) ? *(const v4f*)(b + 16 * t + 4 * q) : V4ZERO;
+}
+
+template <class Core>
+__device__ __forceinline__ void color_forward_body(const msdf_plan_t& plan, const ColorFwdArgs& a, void* lds) {
+  typedef typename Core::wvec wvec;
+  int q;
+  const int pt = wave_point(q);
+  const bool valid = pt < a.P;
+  const int ptc = valid ? pt : a.P - 1;
+  const int ray = ptc / a.spr;
+  const size_t Pp = (size_t)a.P_pad;
+  const int misc_tiles = plan.e_tiles + plan.aux_tiles;
+  const int nu = plan.n_layers;             // pack units
+  v4f in[MT], acc[MT];
+  // ---- first layer, feature part
+  const msdf_layer_t U0 = plan.layer[0];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+    in[t] = (t < U0.kt) ? *(const v4f*)(a.feat + (size_t)ptc * (16 * U0.kt) + 16 * t + 4 * q) : V4ZERO;
+  load_bias_c(acc, a.bpack + U0.bias_off, U0.ot, q);
+  Core::gemm(U0.ktp, acc, in, U0.ot, (const wvec*)a.wpack + U0.wf_off, lds, NoEpilogue());
+  // ---- first layer, misc part (same accumulators)
+  {
+    v4f m[5];
+    color_misc_tiles(m, plan, a.x, a.dirs, a.nrm, a.code, ptc, ray, q);
+    place_tiles(in, 0, m, misc_tiles);
+    if (a.save) {
+#pragma unroll
+      for (int t = 0; t < 5; ++t)
+        if (t < misc_tiles) *(v4f*)(a.MISC + (size_t)pt * (16 * misc_tiles) + 16 * t + 4 * q) = m[t];
+    }
+  }
+  const msdf_layer_t U1 = plan.layer[1];
+  Core::gemm(U1.ktp, acc, in, U1.ot, (const wvec*)a.wpack + U1.wf_off, lds, NoEpilogue());
+  // ---- hidden layers
+  for (int u = 2; u < nu; ++u) {
+    const msdf_layer_t L = plan.layer[u];
+    float* Hl = a.H + (size_t)L.hpre * Pp + (size_t)pt * (16 * L.kt) + 4 * q;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      v4f h = V4ZERO;
+      if (t < L.kt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = fmaxf(acc[t][r], 0.f);
+        if (a.save) *(v4f*)(Hl + 16 * t) = h;
+      }
+      in[t] = h;
+    }
+    load_bias_c(acc, a.bpack + L.bias_off, L.ot, q);
+    Core::gemm(L.ktp, acc, in, L.ot, (const wvec*)a.wpack + L.wf_off, lds, NoEpilogue());
+  }
+  // ---- output activation: slots 0..2 sit in tile 0, quarter 0
+  if (valid && q == 0) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float v = acc[0][r];
+      a.rgb[(size_t)pt * 3 + r] = (plan.out_act == 1) ? fmaxf(v, 0.f) : 1.0f / (1.0f + fast_exp(-v));
+    }
+  }
+}
+
+typedef msdf_color_bwd_args_t ColorBwdArgs;
+
+template <class Core>
+__device__ __forceinline__ void color_backward_body(const msdf_plan_t& plan, const ColorBwdArgs& a, void* lds) {
+  typedef typename Core::wvec wvec;
+  int q;
+  const int pt = wave_point(q);
+  const bool valid = pt < a.P;
+  const size_t Pp = (size_t)a.P_pad;
+  const int nu = plan.n_layers;
+  const int misc_tiles = plan.e_tiles + plan.aux_tiles;
+  v4f in[MT], acc[MT];
+  zero_tiles(in);
+  // ---- a-bar of the output layer
+  {
+    v4f ab = V4ZERO;
+    if (valid && q == 0) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const float y = a.rgb[(size_t)pt * 3 + r];
+        const float g = a.g_rgb[(size_t)pt * 3 + r];
+        ab[r] = (plan.out_act == 1) ? ((y > 0.f) ? g : 0.f) : g * y * (1.0f - y);
+      }
+    }
+    in[0] = ab;
+    const msdf_layer_t LL = plan.layer[nu - 1];
+    float* ABl = a.AB + (size_t)LL.abpre * Pp + (size_t)pt * (16 * LL.ot) + 4 * q;
+    *(v4f*)ABl = ab;
+  }
+  // ---- hidden layers, last to first
+  for (int u = nu - 1; u >= 2; --u) {
+    const msdf_layer_t L = plan.layer[u];
+    zero_tiles(acc);
+    Core::gemm(L.otp, acc, in, L.kt, (const wvec*)a.wpack + L.wb_off, lds, NoEpilogue());
+    // acc = h-bar of this layer's input = output of unit u-1 (u-1 == 1 means the first layer)
+    const float* Hl = a.H + (size_t)L.hpre * Pp + (size_t)pt * (16 * L.kt) + 4 * q;
+    const msdf_layer_t Lp = plan.layer[(u - 1 == 1) ? 0 : u - 1];
+    float* ABl = a.AB + (size_t)Lp.abpre * Pp + (size_t)pt * (16 * Lp.ot) + 4 * q;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      v4f ab = V4ZERO;
+      if (t < L.kt) {
+        const v4f h = *(const v4f*)(Hl + 16 * t);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ab[r] = (h[r] > 0.f) ? acc[t][r] : 0.f;
+        *(v4f*)(ABl + 16 * t) = ab;
+      }
+      in[t] = ab;
+    }
+  }
+  // ---- first layer: gradient of the feature tiles and of the misc block
+  const msdf_layer_t U0 = plan.layer[0];
+  zero_tiles(acc);
+  Core::gemm(U0.otp, acc, in, U0.kt, (const wvec*)a.wpack + U0.wb_off, lds, NoEpilogue());
+  if (valid) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+      if (t < U0.kt) *(v4f*)(a.g_feat + (size_t)pt * (16 * U0.kt) + 16 * t + 4 * q) = acc[t];
+  }
+  const msdf_layer_t U1 = plan.layer[1];
+  zero_tiles(acc);
+  Core::gemm(U1.otp, acc, in, U1.kt, (const wvec*)a.wpack + U1.wb_off, lds, NoEpilogue());
+  if (valid) {
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+      if (t < misc_tiles) *(v4f*)(a.g_misc + (size_t)pt * (16 * misc_tiles) + 16 * t + 4 * q) = acc[t];
+  }
+}
+

@@ -186,6 +186,187 @@ msdf_wgrad_k(const msdf_wgrad_item_t* __restrict__ items, const int* __restrict_
     part[it.vrow_off + (size_t)split * it.wy + (tid - 256)] = vrow;
 }
 
+// ---------------------------------------------------------------------------
+// bf16x3 variant: the same items on v_mfma_f32_16x16x32_bf16 (x*y ~ x_hi*y_hi + x_hi*y_lo + x_lo*y_hi).
+//
+// Both operands of this GEMM are activations (K = points), so the hi/lo split cannot be precomputed the
+// way the weight packs are.  Each element is split ONCE per workgroup: a thread loads the 8 points x 1 slot
+// an MFMA lane needs (row-wise coalesced dword loads, issued one stage ahead), splits them, and writes the
+// two 16-byte fragments-to-be into a fragment-ordered LDS image; every wave then fetches its A / B fragments
+// with single ds_read_b128s.  Image of one stage (32 points): [X | Y][16 slot tiles][hi | lo][64 lanes] x 16 B
+// = 64 KB, double buffered; lane = 16 * (point octet) + (slot & 15), element j = point 8 * octet + j.
+// ---------------------------------------------------------------------------
+typedef __bf16 wv8bf __attribute__((ext_vector_type(8)));
+typedef float wv4f __attribute__((ext_vector_type(4)));
+
+#define WB_NP 32
+#define WB_IMG_V8 (2 * 16 * 2 * 64)              // 16-byte elements per stage image
+#define WB_LDS_BYTES (2 * WB_IMG_V8 * 16)        // 128 KB
+
+__device__ __forceinline__ void wb_split8(const float (&v)[8], wv8bf& hi, wv8bf& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 h = (__bf16)v[j];
+    hi[j] = h;
+    lo[j] = (__bf16)(v[j] - (float)h);
+  }
+}
+
+__global__ void __launch_bounds__(WG_THREADS, 2)
+msdf_wgrad_b16_k(const msdf_wgrad_item_t* __restrict__ items, const int* __restrict__ wg_map,
+                 const float* __restrict__ ws, float* __restrict__ part, const int P_pad) {
+  extern __shared__ wv8bf lds_img[];
+  const msdf_wgrad_item_t it = items[wg_map[2 * blockIdx.x]];
+  const int split = wg_map[2 * blockIdx.x + 1];
+  const int n_splits = it.n_splits;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // wide items: 2 x 4 waves of 128 rows x 64 cols (8 x 4 tiles); narrow (wy <= 64): 8 x 1 waves of 32 x 64
+  const bool narrow = it.wy <= 64;
+  const int wi = narrow ? wave : (wave >> 2), wj = narrow ? 0 : (wave & 3);
+  const int i_base = narrow ? 32 * wi : 128 * wi, j_base = 64 * wj;
+  const int na = narrow ? 2 : 8;
+
+  const int n_stages_total = P_pad / WB_NP;
+  const int per = (n_stages_total + n_splits - 1) / n_splits;
+  const int s_begin = split * per;
+  const int s_end = min(n_stages_total, s_begin + per);
+  const int n_st = max(0, s_end - s_begin);
+
+  const float* X = ws + it.x_off;
+  const float* Y = ws + it.y_off;
+  const float* V = (it.v_off >= 0) ? ws + it.v_off : nullptr;
+  const bool do_mm = it.wy > 0;
+  const bool want_vrow = it.vrow_off >= 0;
+
+  wv4f acc[8][4];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (wv4f){0.f, 0.f, 0.f, 0.f};
+  bool bj[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) bj[b] = (j_base + 16 * b) < it.wy;
+  const bool wave_active = do_mm && i_base < it.wx && bj[0];
+
+  // loader role: slot `ls`, point octets kh and kh + 2 of both operands
+  const int ls = tid & 255, kh = tid >> 8;
+  const bool lx = ls < it.wx, ly = do_mm && ls < it.wy;
+  float xr[2][8], yr[2][8];
+  float colsum = 0.f, vrow = 0.f;
+
+  auto load = [&](const int j) {
+    const size_t p0 = (size_t)(s_begin + j) * WB_NP;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const size_t pu = p0 + 8 * (kh + 2 * u);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        xr[u][e] = lx ? X[(pu + e) * it.x_ld + ls] : 0.f;
+        yr[u][e] = ly ? Y[(pu + e) * it.y_ld + ls] : 0.f;
+      }
+    }
+  };
+  auto store = [&](const int j) {
+    wv8bf* img = lds_img + (j & 1) * WB_IMG_V8;
+    const size_t p0 = (size_t)(s_begin + j) * WB_NP;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int kq = kh + 2 * u;
+      const int fl = (ls >> 4) * 128 + kq * 16 + (ls & 15);       // [tile][hi|lo][lane]
+      wv8bf hi, lo;
+      wb_split8(xr[u], hi, lo);
+      img[fl] = hi;
+      img[fl + 64] = lo;
+      if (do_mm) {
+        wb_split8(yr[u], hi, lo);
+        img[16 * 128 + fl] = hi;
+        img[16 * 128 + fl + 64] = lo;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) colsum += xr[u][e];
+      if (want_vrow) {
+        const wv4f v0 = *(const wv4f*)(V + p0 + 8 * kq), v1 = *(const wv4f*)(V + p0 + 8 * kq + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vrow += v0[e] * yr[u][e] + v1[e] * yr[u][4 + e];
+      }
+    }
+  };
+
+  if (n_st > 0) load(0);
+  for (int j = 0; j < n_st; ++j) {
+    store(j);
+    if (j + 1 < n_st) load(j + 1);          // in flight behind this stage's matrix products
+    __syncthreads();                        // image j complete; image j-1's readers passed the previous barrier
+    if (wave_active) {
+      const wv8bf* img = lds_img + (j & 1) * WB_IMG_V8 + lane;
+      wv8bf bh[4], bl[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int tn = (j_base >> 4) + b;
+        bh[b] = img[16 * 128 + tn * 128];
+        bl[b] = img[16 * 128 + tn * 128 + 64];
+      }
+      wv8bf ah = img[(i_base >> 4) * 128], al = img[(i_base >> 4) * 128 + 64];
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        if (a < na && (i_base + 16 * a) < it.wx) {
+          wv8bf nh = ah, nl = al;
+          if (a + 1 < 8 && a + 1 < na) {
+            nh = img[((i_base >> 4) + a + 1) * 128];
+            nl = img[((i_base >> 4) + a + 1) * 128 + 64];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            if (bj[b]) {
+              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[b], acc[a][b], 0, 0, 0);
+              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[b], acc[a][b], 0, 0, 0);
+              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[b], acc[a][b], 0, 0, 0);
+            }
+          }
+          ah = nh;
+          al = nl;
+        }
+      }
+    }
+  }
+
+  // ---------------- write this split's partials ----------------
+  if (wave_active) {
+    float* out = part + it.part_off + (size_t)split * it.wx * it.wy;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        if (a < na && bj[b]) {
+          const int n = j_base + 16 * b + (lane & 15);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = i_base + 16 * a + 4 * (lane >> 4) + r;
+            if (m < it.wx && n < it.wy) out[(size_t)m * it.wy + n] = acc[a][b][r];
+          }
+        }
+      }
+    }
+  }
+  // column sums / v-weighted sums: two loader threads per slot, added in a fixed order through LDS
+  if (it.colsum_off >= 0 || want_vrow) {
+    __syncthreads();
+    float* red = (float*)lds_img;
+    red[kh * 256 + ls] = colsum;
+    red[512 + kh * 256 + ls] = vrow;
+    __syncthreads();
+    if (tid < 256) {
+      if (it.colsum_off >= 0 && tid < it.wx)
+        part[it.colsum_off + (size_t)split * it.wx + tid] = red[tid] + red[256 + tid];
+      if (want_vrow && tid < it.wy)
+        part[it.vrow_off + (size_t)split * it.wy + tid] = red[512 + tid] + red[768 + tid];
+    }
+  }
+}
+
 // dst[rowmap[i]*ld + colmap[j]] = scale * sum_b PART[b][i][j]   (fixed summation order)
 __global__ void __launch_bounds__(256)
 msdf_reduce_k(const msdf_reduce_rule_t* __restrict__ rules, const int* __restrict__ maps,
@@ -205,9 +386,18 @@ msdf_reduce_k(const msdf_reduce_rule_t* __restrict__ rules, const int* __restric
 }
 
 extern "C" int msdf_wgrad(const msdf_wgrad_item_t* items_dev, const int32_t* wg_map_dev, int n_wgs,
-                          const float* workspace, float* partials, int P_pad, void* stream) {
-  if (n_wgs < 0 || P_pad < 0 || (P_pad % WG_NP) != 0) return MSDF_ERR_ARG;
+                          const float* workspace, float* partials, int P_pad, int precision, void* stream) {
+  if (n_wgs < 0 || P_pad < 0 || (P_pad % WB_NP) != 0) return MSDF_ERR_ARG;
   if (n_wgs == 0 || P_pad == 0) return MSDF_OK;
+  if (precision == MSDF_PRECISION_BF16X3) {
+    if (hipFuncSetAttribute((const void*)msdf_wgrad_b16_k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            WB_LDS_BYTES) != hipSuccess)
+      return MSDF_ERR_LAUNCH;
+    msdf_wgrad_b16_k<<<n_wgs, WG_THREADS, WB_LDS_BYTES, (hipStream_t)stream>>>(items_dev, wg_map_dev, workspace,
+                                                                               partials, P_pad);
+    return msdf_check_launch();
+  }
+  if (precision != MSDF_PRECISION_F32) return MSDF_ERR_ARG;
   if (hipFuncSetAttribute((const void*)msdf_wgrad_k, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS_BYTES) !=
       hipSuccess)
     return MSDF_ERR_LAUNCH;

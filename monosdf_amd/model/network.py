@@ -265,6 +265,8 @@ class ImplicitNetworkGrid(_SdfBase):
 
 
 class RenderingNetwork(_FusedNet):
+    supports_bf16x3 = True
+
     def __init__(self, feature_vector_size, mode, d_in, d_out, dims, weight_norm=True, multires_view=0,
                  per_image_code=False, if_hdr=False, spec=False, debug=False):
         super().__init__()

@@ -114,7 +114,7 @@ class FusedMlp:
         st = _lib.stream_ptr()
         wg_map = ent['wg_map']
         _lib.call('msdf_wgrad', _lib.ptr(items_dev), _lib.ptr(wg_map), wg_map.numel() // 2, None, _lib.ptr(part),
-                  P_pad, st)
+                  P_pad, PRECISIONS.index(self.precision), st)
         _lib.call('msdf_reduce', _lib.ptr(ent['rules']), len(prog.rules), _lib.ptr(self.maps_dev),
                   _lib.ptr(part), _lib.ptr(grad), st)
         return grad

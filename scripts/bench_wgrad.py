@@ -14,6 +14,7 @@ P_pad = 104448
 woff, total = planlib.sdf_workspace(mp, P_pad)
 ws = torch.randn(total, device=dev) * 0.01
 flops = None
+PREC = 0
 
 def run(split_fn, label, iters=5):
     prog = planlib.build_sdf_wgrad(mp, P_pad, split_fn)
@@ -23,16 +24,17 @@ def run(split_fn, label, iters=5):
     st = _lib.stream_ptr()
     macs = sum(it['wx'] * it['wy'] for it in prog.items) * P_pad
     def once():
-        _lib.call('msdf_wgrad', _lib.ptr(items), _lib.ptr(wg_map), wg_map.numel() // 2, None, _lib.ptr(part), P_pad, st)
+        _lib.call('msdf_wgrad', _lib.ptr(items), _lib.ptr(wg_map), wg_map.numel() // 2, None, _lib.ptr(part), P_pad, PREC, st)
     once(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters): once()
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    print('%-28s WGs %4d  %.3f ms  %.1f TFLOP/s' % (label, wg_map.numel() // 2, ms, 2 * macs / ms / 1e9))
+    print('%-34s WGs %4d  %.3f ms  %.1f TFLOP/s' % (label, wg_map.numel() // 2, ms, 2 * macs / ms / 1e9))
 
 prog = planlib.balanced_program(planlib.build_sdf_wgrad, mp, P_pad)
 print('balanced: WGs', len(prog.wg_map()) // 2, sorted(set((it['weight'], it['n_splits']) for it in prog.items)))
-for S in (16, 32, 48, 64, 96, 128):
-    run(lambda w, S=S: S, 'all items S=%d' % S)
+for PREC in (0, 1):
+    for S in (16, 32, 48, 64, 96, 128):
+        run(lambda w, S=S: S, '%s all items S=%d' % (ops.PRECISIONS[PREC], S))

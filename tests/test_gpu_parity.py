@@ -79,16 +79,19 @@ def test_sdf_network_double_backward(name, precision):
     assert abs(loss.item() - loss_o.item()) < 1e-4 * max(1.0, scale)
     loss.backward()
     params = dict(m.named_parameters())
+    # second-order parameter gradients: 2e-4 on the fp32 core; the bf16x3 core drops the lo*lo term of every
+    # product (2^-16 relative) and measures up to 2.3e-4 on weight_g (a row sum with cancellation) -> 5e-4
+    gtol = 2e-4 if precision == 'fp32' else 5e-4
     for n, go in zip(names, g_o):
         assert params[n].grad is not None, n
-        assert rel_err(params[n].grad, go) < 2e-4, (n, rel_err(params[n].grad, go))
+        assert rel_err(params[n].grad, go) < gtol, (n, rel_err(params[n].grad, go))
 
 
-def test_color_network_forward_backward():
+def test_color_network_forward_backward(precision):
     from oracle import monosdf_oracle as mo
     for name in ['mlp_w64_eval', 'mlp_w256_eval', 'mlp_w64_code_train']:
         c = Case(name)
-        m = _model(c, training=True)
+        m = _model(c, training=True, precision=precision)
         g = torch.Generator().manual_seed(7)
         n_rays, S = 12, 9
         P = n_rays * S
