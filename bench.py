@@ -10,7 +10,9 @@ Weak scaling: every rank renders its own 1024-ray batch, gradients are averaged 
 all-reduce of the flat 2.7 MB gradient, as the reference's DDP does.
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed inside the timed
-region) and `cpu_baseline` (the CPU oracle on a bounded sample, rank 0, N=1 only).
+region) and `cpu_baseline` (the CPU oracle on a bounded sample, rank 0, N=1 only).  `value` is measured
+on the fp32 MFMA core (--precision fp32, the default); the same K steps are then repeated on the bf16x3
+core and reported under `alt_matrix_core` (never mixed into `value`).
 """
 import argparse
 import json
@@ -128,6 +130,10 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--config', choices=['mlp', 'grid'], default='mlp',
                     help="mlp = BASELINE.json configs[1] (the headline metric); grid = configs[2] (hash-grid path)")
+    ap.add_argument('--precision', choices=['fp32', 'bf16x3'], default=os.environ.get('MONOSDF_PRECISION', 'fp32'),
+                    help='matrix core of the fused MLP kernels that `value` is measured on (default fp32 MFMA)')
+    ap.add_argument('--no-alt-precision', dest='alt_precision', action='store_false',
+                    help='skip the second measurement on the other matrix core (reported under alt_matrix_core)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -140,60 +146,66 @@ def main():
         import torch.distributed as dist
         dist.init_process_group(backend='nccl', init_method='env://', device_id=device)
 
-    from monosdf_amd import _lib, parallel
+    from monosdf_amd import _lib, ops, parallel
     from monosdf_amd.model.network import MonoSDFNetwork
-
-    torch.manual_seed(0)                      # same initial weights on every rank (as DDP would broadcast)
-    model = MonoSDFNetwork(model_conf(grid=(args.config == 'grid'))).to(device).train()
-    params = [p for p in model.parameters() if p.requires_grad]
-    try:
-        opt = torch.optim.Adam(params, lr=5e-4, fused=True)      # one multi-tensor launch for the whole update
-    except (RuntimeError, TypeError):
-        opt = torch.optim.Adam(params, lr=5e-4)
-    torch.manual_seed(1234 + rank)            # per-rank sampling noise
-    rays = make_rays(N_RAYS, 1 + rank, device)
-    indices = torch.arange(N_RAYS, device=device)
-
-    from monosdf_amd import ops
-
-    def step():
-        opt.zero_grad(set_to_none=True)
-        out = model(rays, indices, if_pixel_input=True)
-        loss = ops.probe_loss(out)        # the BASELINE.md probe loss, value + gradients in one HIP launch
-        loss.backward()
-        parallel.average_gradients(params)        # one flat RCCL all-reduce (no-op on one GPU)
-        opt.step()
-        return loss
-
-    for _ in range(args.warmup):
-        step()
-    rounds = model.ray_sampler.last_rounds
 
     def barrier():
         if use_dist:
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
-    _lib.PROFILE = {}
-    barrier()
-    t0 = time.time()
-    for _ in range(args.steps):
-        loss = step()
-    barrier()
-    dt = time.time() - t0
-    prof, _lib.PROFILE = _lib.PROFILE, None
-    if use_dist:
-        t = torch.tensor([dt], device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def measure(precision):
+        """W warm-up + K timed steps of the training step on the given matrix core; returns the max over ranks."""
+        torch.manual_seed(0)                      # same initial weights on every rank (as DDP would broadcast)
+        model = MonoSDFNetwork(model_conf(grid=(args.config == 'grid'))).to(device).train()
+        model.set_precision(precision)
+        params = [p for p in model.parameters() if p.requires_grad]
+        try:
+            opt = torch.optim.Adam(params, lr=5e-4, fused=True)      # one multi-tensor launch for the whole update
+        except (RuntimeError, TypeError):
+            opt = torch.optim.Adam(params, lr=5e-4)
+        torch.manual_seed(1234 + rank)            # per-rank sampling noise
+        rays = make_rays(N_RAYS, 1 + rank, device)
+        indices = torch.arange(N_RAYS, device=device)
 
-    if rank == 0:
+        def step():
+            opt.zero_grad(set_to_none=True)
+            out = model(rays, indices, if_pixel_input=True)
+            loss = ops.probe_loss(out)        # the BASELINE.md probe loss, value + gradients in one HIP launch
+            loss.backward()
+            parallel.average_gradients(params)        # one flat RCCL all-reduce (no-op on one GPU)
+            opt.step()
+            return loss
+
+        for _ in range(args.warmup):
+            step()
+        rounds = model.ray_sampler.last_rounds
+        _lib.PROFILE = {}
+        barrier()
+        t0 = time.time()
+        for _ in range(args.steps):
+            loss = step()
+        barrier()
+        dt = time.time() - t0
+        prof, _lib.PROFILE = _lib.PROFILE, None
+        if use_dist:
+            t = torch.tensor([dt], device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
         # per-entry-point device time (HIP events on the launch stream, inside the timed region)
         kern = {}
         for name, evs in prof.items():
             ms = [a.elapsed_time(b) for a, b in evs]
             kern[name] = {'launches_per_step': len(ms) / args.steps, 'avg_ms': float(np.mean(ms)),
                           'ms_per_step': float(np.sum(ms)) / args.steps}
+        plan = model.implicit_network._fused(device).mp.plan
+        return dict(dt=dt, kern=kern, rounds=rounds, loss=float(loss.item()),
+                    slots=(plan.hsum, plan.qsum, plan.absum))
+
+    def mlp_rooflines(m):
+        """Roofline of the dominant SDF kernel.  fp32 core: MFMA-bound (algorithmic FLOPs, SURVEY.md 8(d));
+        bf16x3 core: the same kernels are HBM-bound on their saved-activation traffic."""
+        kern = m['kern']
         P_main, P_eik, P_smp = N_RAYS * 98, 4 * N_RAYS, N_RAYS * 128
         F = sdf_macs_per_point()
         flops = {   # algorithmic FLOPs per launch (2 FLOP / MAC), SURVEY.md 8(d) multipliers
@@ -201,28 +213,67 @@ def main():
             'msdf_sdf_fwd_grad': 2.0 * 2 * F * (P_main + P_eik),   # forward + d/dx sweep
             'msdf_sdf_backward': 2.0 * 2 * F * (P_main + P_eik),   # p-bar = W q-bar and h-bar = W^T a-bar sweeps
         }
+        hs, qs, ab = m['slots']
+        P = P_main + P_eik
+        hbm = {     # algorithmic bytes per launch: 4 B x slots read or written per point
+            'msdf_sdf_fwd_grad': 4.0 * P * (3 * hs),               # H written, H re-read, PM written
+            'msdf_sdf_backward': 4.0 * P * (5 * hs + qs + ab),     # H x2, PM, T read; T, QB, AB written
+        }
+        dom = max((n for n in kern if n in flops), key=lambda n: kern[n]['ms_per_step'])
+        t = kern[dom]['avg_ms'] * 1e-3
+        mf = {'bound': 'mfma', 'kernel': dom, 'achieved': flops[dom] / t / 1e12, 'peak': F32_MFMA_PEAK_TFLOPS,
+              'unit': 'TFLOP/s', 'frac': flops[dom] / t / 1e12 / F32_MFMA_PEAK_TFLOPS, 'traffic': None,
+              'avg_kernel_ms': kern[dom]['avg_ms']}
+        if dom == 'msdf_sdf_backward':
+            # rocprofv3 FETCH_SIZE(x2)+WRITE_SIZE of this kernel, profiles/r01_v3_pmc_summary.json (same data movement)
+            mf['traffic'] = 6.55e9
+        hb = None
+        if dom in hbm:
+            hb = {'bound': 'hbm', 'kernel': dom, 'achieved': hbm[dom] / t / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
+                  'frac': hbm[dom] / t / 1e9 / 8000.0, 'traffic': mf['traffic'], 'avg_kernel_ms': kern[dom]['avg_ms']}
+        return mf, hb
+
+    primary = measure(args.precision)
+    alt = None
+    if args.alt_precision and args.config == 'mlp':
+        alt = measure('bf16x3' if args.precision == 'fp32' else 'fp32')
+
+    if rank == 0:
+        kern, dt, rounds = primary['kern'], primary['dt'], primary['rounds']
+        dtype = 'f32' if args.precision == 'fp32' else 'bf16x3 (fp32 split into 2 bf16, fp32 accumulate)'
         if args.config == 'grid':
-            print(json.dumps(grid_report(args, kern, dt, world, rounds, float(loss.item()))))
+            res = grid_report(args, kern, dt, world, rounds, primary['loss'])
+            res['dtype'] = dtype
+            print(json.dumps(res))
             if use_dist:
                 dist.destroy_process_group()
             return
-        dom = max((n for n in kern if n in flops), key=lambda n: kern[n]['ms_per_step'])
-        achieved = flops[dom] / (kern[dom]['avg_ms'] * 1e-3) / 1e12
+        mf, hb = mlp_rooflines(primary)
         res = {
             'metric': 'rays/sec fwd+bwd, 1024 rays x 98 samples, 8x256 SDF MLP',
             'value': world * N_RAYS * args.steps / dt, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
             'config': {'workload': 'configs[1]: 1024 rays x 98 samples per GPU, ImplicitNetwork 8x256 + '
                                    'RenderingNetwork 289-256-256-3, error-bounded sampler (k=%d round), '
                                    'training step = fwd + loss + bwd + Adam' % rounds,
-                       'rays_per_gpu': N_RAYS, 'samples_per_ray': 98, 'sampler_rounds': rounds},
-            'roofline': {'bound': 'mfma', 'kernel': dom, 'achieved': achieved, 'peak': F32_MFMA_PEAK_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': achieved / F32_MFMA_PEAK_TFLOPS, 'traffic': None,
-                         'avg_kernel_ms': kern[dom]['avg_ms']},
+                       'rays_per_gpu': N_RAYS, 'samples_per_ray': 98, 'sampler_rounds': rounds,
+                       'matrix_core': args.precision},
+            'roofline': mf if args.precision == 'fp32' else (hb or mf),
             'kernels_ms_per_step': {k: round(v['ms_per_step'], 4) for k, v in sorted(kern.items())},
-            'loss': float(loss.item()),
+            'loss': primary['loss'],
         }
+        if alt is not None:
+            amf, ahb = mlp_rooflines(alt)
+            other = 'bf16x3' if args.precision == 'fp32' else 'fp32'
+            res['alt_matrix_core'] = {
+                'matrix_core': other, 'value': world * N_RAYS * args.steps / alt['dt'], 'unit': 'rays/s',
+                'ms_per_step': 1e3 * alt['dt'] / args.steps,
+                'roofline': (ahb or amf) if other == 'bf16x3' else amf,
+                'kernels_ms_per_step': {k: round(v['ms_per_step'], 4) for k, v in sorted(alt['kern'].items())},
+                'note': 'same workload, steps and warm-up on the other matrix core of the fused MLP kernels; both '
+                        'pass the same parity tests (tests/test_gpu_parity.py); `value` above is the %s core' % args.precision,
+            }
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline()
         print(json.dumps(res))

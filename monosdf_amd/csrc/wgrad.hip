@@ -367,21 +367,29 @@ msdf_wgrad_b16_k(const msdf_wgrad_item_t* __restrict__ items, const int* __restr
   }
 }
 
-// dst[rowmap[i]*ld + colmap[j]] = scale * sum_b PART[b][i][j]   (fixed summation order)
+// dst[rowmap[i]*ld + colmap[j]] = scale * sum_b PART[b][i][j]   (fixed summation order: b ascending, so the
+// result is bitwise reproducible).  Four consecutive elements per thread (16-byte loads; wx*wy is a multiple
+// of 16) and the block loop unrolled so that 8 loads are in flight before the first add.
 __global__ void __launch_bounds__(256)
 msdf_reduce_k(const msdf_reduce_rule_t* __restrict__ rules, const int* __restrict__ maps,
                    const float* __restrict__ part, float* __restrict__ dst) {
+  typedef float rv4f __attribute__((ext_vector_type(4)));
   const msdf_reduce_rule_t R = rules[blockIdx.y];
   const int n = R.wx * R.wy;
-  const float* src = part + R.part_off;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
-    const int i = e / R.wy, j = e - i * R.wy;
-    const int row = (R.rowmap_off >= 0) ? maps[R.rowmap_off + i] : R.fixed_row;
-    const int col = (R.colmap_off >= 0) ? maps[R.colmap_off + j] : 0;
-    if (row < 0 || col < 0) continue;
-    float s = 0.f;
-    for (int b = 0; b < R.n_blocks; ++b) s += src[(size_t)b * n + e];
-    dst[R.dst_off + (size_t)row * R.dst_ld + col] = R.scale * s;
+  const int n4 = n >> 2;
+  const rv4f* src = (const rv4f*)(part + R.part_off);
+  for (int e4 = blockIdx.x * blockDim.x + threadIdx.x; e4 < n4; e4 += gridDim.x * blockDim.x) {
+    rv4f s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int b = 0; b < R.n_blocks; ++b) s += src[(size_t)b * n4 + e4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int e = 4 * e4 + c;
+      const int i = e / R.wy, jj = e - i * R.wy;
+      const int row = (R.rowmap_off >= 0) ? maps[R.rowmap_off + i] : R.fixed_row;
+      const int col = (R.colmap_off >= 0) ? maps[R.colmap_off + jj] : 0;
+      if (row >= 0 && col >= 0) dst[R.dst_off + (size_t)row * R.dst_ld + col] = R.scale * s[c];
+    }
   }
 }
 

@@ -31,12 +31,17 @@ PRECISIONS = ('fp32', 'bf16x3')
 
 
 # ---------------------------------------------------------------------------
-# side stream: the colour network's weight-gradient GEMM does not feed the SDF backward kernel, and that
-# kernel's last round fills only a fifth of the chip (1632 workgroups on 512 slots) -- so the two overlap.
+# side stream: the colour network's weight-gradient GEMM feeds nothing but the optimiser, and the SDF network's
+# weight-gradient launch ends with a partly filled chip (1344 workgroups on 256 slots), so the two run side
+# by side.  ColorMlpFunction.backward only queues its launch; SdfMlpFunction.backward starts it on the side
+# stream right after the SDF backward kernel, next to its own weight-gradient launch; the first consumer of
+# the gradients (FusedWeightNormFunction.backward) joins.  Without an SDF backward in the graph the queued
+# launch simply runs at the join, on the main stream.
 # ---------------------------------------------------------------------------
 import os as _os
 
 _SIDE_STREAMS = {}
+_DEFERRED = []         # launches queued for the side stream: callables
 _PENDING = []          # events of side-stream work whose results the main stream has not waited for yet
 USE_SIDE_STREAM = _os.environ.get('MSDF_SIDE_STREAM', '1') != '0'
 
@@ -48,8 +53,28 @@ def _side_stream(device):
     return _SIDE_STREAMS[key]
 
 
+def start_side_work(device):
+    """Launch everything queued on the side stream, ordered after the work already on the current stream."""
+    if not _DEFERRED:
+        return
+    main, side = torch.cuda.current_stream(), _side_stream(device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        for launch in _DEFERRED:
+            launch(side)
+        done = torch.cuda.Event()
+        done.record(side)
+    _DEFERRED.clear()
+    _PENDING.append(done)
+
+
 def join_side_work():
-    """Make the current stream wait for everything queued on the side stream (cheap when there is nothing)."""
+    """Make the current stream wait for the side stream (cheap when there is nothing to wait for)."""
+    if _DEFERRED:                      # nobody started it: run it here, in order
+        cur = torch.cuda.current_stream()
+        for launch in _DEFERRED:
+            launch(cur)
+        _DEFERRED.clear()
     if _PENDING:
         cur = torch.cuda.current_stream()
         for ev in _PENDING:
@@ -98,8 +123,10 @@ class FusedMlp:
             self._wgrad_cache[key] = dict(prog=prog, rules=rules_dev, wg_map=wg_map, items={})
         return self._wgrad_cache[key]
 
-    def run_wgrad(self, P_pad, base_addr):
-        """base_addr: buffer name -> tensor.  Returns the flat gradient [n_w + n_b]."""
+    def run_wgrad(self, P_pad, base_addr, defer=False):
+        """base_addr: buffer name -> tensor.  Returns the flat gradient [n_w + n_b].
+        defer: only queue the two launches (start_side_work / join_side_work run them); the returned tensor
+        is filled by then."""
         ent = self.wgrad_program(P_pad)
         prog = ent['prog']
         addr = {k: t.data_ptr() for k, t in base_addr.items()}
@@ -111,12 +138,23 @@ class FusedMlp:
         items_dev = ent['items'][key]
         part = torch.empty(prog.part_f + 64, device=self.device, dtype=torch.float32)
         grad = torch.zeros(self.mp.n_w + self.mp.n_b, device=self.device, dtype=torch.float32)
-        st = _lib.stream_ptr()
         wg_map = ent['wg_map']
-        _lib.call('msdf_wgrad', _lib.ptr(items_dev), _lib.ptr(wg_map), wg_map.numel() // 2, None, _lib.ptr(part),
-                  P_pad, PRECISIONS.index(self.precision), st)
-        _lib.call('msdf_reduce', _lib.ptr(ent['rules']), len(prog.rules), _lib.ptr(self.maps_dev),
-                  _lib.ptr(part), _lib.ptr(grad), st)
+        held = list(base_addr.values())
+
+        def launch(stream=None):
+            if stream is not None:
+                for t in held + [part, grad]:
+                    t.record_stream(stream)      # allocated on the main stream, used on this one
+            st = _lib.stream_ptr()
+            _lib.call('msdf_wgrad', _lib.ptr(items_dev), _lib.ptr(wg_map), wg_map.numel() // 2, None,
+                      _lib.ptr(part), P_pad, PRECISIONS.index(self.precision), st)
+            _lib.call('msdf_reduce', _lib.ptr(ent['rules']), len(prog.rules), _lib.ptr(self.maps_dev),
+                      _lib.ptr(part), _lib.ptr(grad), st)
+
+        if defer:
+            _DEFERRED.append(launch)
+        else:
+            launch()
         return grad
 
 
@@ -295,6 +333,7 @@ class SdfMlpFunction(torch.autograd.Function):
         b.g_aux = g_aux.data_ptr() if g_aux is not None else None
         if P > 0:
             _lib.call('msdf_sdf_backward', C.byref(plan), C.byref(b), _lib.stream_ptr())
+            start_side_work(dev)                 # the colour network's queued weight-gradient launch, if any
             grad = mlp.run_wgrad(P_pad, {'ws': ws})
         else:
             grad = torch.zeros(mp.n_w + mp.n_b, device=dev)
@@ -369,19 +408,7 @@ class ColorMlpFunction(torch.autograd.Function):
         b.g_feat, b.g_misc = g_feat.data_ptr(), g_misc.data_ptr()
         if P > 0:
             _lib.call('msdf_color_backward', C.byref(plan), C.byref(b), _lib.stream_ptr())
-            if USE_SIDE_STREAM:
-                main, side = torch.cuda.current_stream(), _side_stream(dev)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    grad = cmlp.run_wgrad(P_pad, {'ws': ws, 'feat': feat})
-                    done = torch.cuda.Event()
-                    done.record(side)
-                for t in (ws, feat):
-                    t.record_stream(side)       # saved tensors are released before the side stream is done
-                grad.record_stream(main)
-                _PENDING.append(done)
-            else:
-                grad = cmlp.run_wgrad(P_pad, {'ws': ws, 'feat': feat})
+            grad = cmlp.run_wgrad(P_pad, {'ws': ws, 'feat': feat}, defer=USE_SIDE_STREAM)
         else:
             grad = torch.zeros(mp.n_w + mp.n_b, device=dev)
         g_nrm = g_misc[:, mp.lead - 3:mp.lead].contiguous() if plan.mode == 1 else None
