@@ -267,6 +267,13 @@ int msdf_sampler_beta(const msdf_sampler_args_t* args, void* stream);
 int msdf_sampler_resample(const msdf_sampler_args_t* args, void* stream);
 int msdf_sampler_finish(const msdf_sampler_args_t* args, void* stream);
 
+/* ---- ray generation (reference: utils/rend_util.py:63-91,105-118 as called at
+ * model/network.py:505-516).  uv [n,2] pixel coordinates, pose [4,4] camera-to-world, intrinsics [4,4];
+ * outputs: ray_dirs [n,3] world-space unit directions, ray_dirs_cam [n,3] the same ray in the camera frame
+ * (the reference's `ray_dirs_tmp`; its z is the depth scale), cam_loc [n,3] the camera centre per ray. */
+int msdf_camera_rays(const float* uv, const float* pose, const float* intrinsics, int n, float* ray_dirs,
+                     float* ray_dirs_cam, float* cam_loc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

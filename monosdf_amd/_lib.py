@@ -138,6 +138,7 @@ _SIGNATURES = {
     'msdf_color_forward': [C.POINTER(Plan), C.POINTER(ColorFwdArgs), _P],
     'msdf_color_backward': [C.POINTER(Plan), C.POINTER(ColorBwdArgs), _P],
     'msdf_wgrad': [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, _P],
+    'msdf_camera_rays': [_P, _P, _P, C.c_int, _P, _P, _P, _P],
     'msdf_reduce': [_P, C.c_int, _P, _P, _P, _P],
     'msdf_composite_forward': [C.POINTER(CompositeArgs), _P],
     'msdf_composite_backward': [C.POINTER(CompositeBwdArgs), _P],

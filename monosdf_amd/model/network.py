@@ -358,12 +358,12 @@ class MonoSDFNetwork(nn.Module):
     # -- rays ------------------------------------------------------------------------------
     def _rays(self, input_dict, if_pixel_input):
         if not if_pixel_input:
-            from ..utils import rend_util
+            # one launch for both get_camera_params calls of the reference (network.py:505-516)
             uv, pose, intrinsics = input_dict['uv'], input_dict['pose'], input_dict['intrinsics']
-            ray_dirs, cam_loc = rend_util.get_camera_params(uv, pose, intrinsics)
-            eye = torch.eye(4, device=pose.device, dtype=pose.dtype)[None]
-            ray_dirs_tmp, _ = rend_util.get_camera_params(uv, eye, intrinsics)
-            cam_loc = cam_loc.unsqueeze(1).repeat(1, ray_dirs.shape[1], 1).reshape(-1, 3)
+            if uv.shape[0] != 1:
+                raise NotImplementedError('image mode renders one image (one pose) per call, as the runner does')
+            ray_dirs, ray_dirs_tmp, cam_loc = ops.camera_rays(uv[0], pose[0], intrinsics[0])
+            ray_dirs, ray_dirs_tmp = ray_dirs.unsqueeze(0), ray_dirs_tmp.unsqueeze(0)
         else:
             ray_dirs = input_dict['ray_dirs'].unsqueeze(0)
             cam_loc = input_dict['ray_cam_loc']

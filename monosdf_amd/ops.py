@@ -621,3 +621,23 @@ class ProbeLossFunction(torch.autograd.Function):
 def probe_loss(out, w_normal=0.05, w_depth=0.1, w_eik=0.05, w_smooth=0.005):
     return ProbeLossFunction.apply(out['rgb_values'], out['normal_map'], out['depth_values'], out['grad_theta'],
                                    out['grad_theta_nei'], w_normal, w_depth, w_eik, w_smooth)
+
+
+# ---------------------------------------------------------------------------
+# ray generation (image-mode inputs)
+# ---------------------------------------------------------------------------
+def camera_rays(uv, pose, intrinsics):
+    """uv [n,2], pose [4,4], intrinsics [4,4] -> (ray_dirs [n,3], ray_dirs_cam [n,3], cam_loc [n,3]);
+    rend_util.get_camera_params with the pose and with the identity in one launch (no gradients: the
+    reference's poses / intrinsics are data)."""
+    uv = _need_cuda(uv.detach(), 'uv')
+    pose = _need_cuda(pose.detach(), 'pose')
+    intrinsics = _need_cuda(intrinsics.detach(), 'intrinsics')
+    if pose.shape != (4, 4) or intrinsics.shape != (4, 4):
+        raise NotImplementedError('monosdf_amd: 4x4 pose / intrinsics matrices only (quaternion poses are not '
+                                  'used on this path)')
+    n = uv.shape[0]
+    out = torch.empty(3, n, 3, device=uv.device, dtype=torch.float32)
+    _lib.call('msdf_camera_rays', _lib.ptr(uv), _lib.ptr(pose), _lib.ptr(intrinsics), n, _lib.ptr(out[0]),
+              _lib.ptr(out[1]), _lib.ptr(out[2]), _lib.stream_ptr())
+    return out[0], out[1], out[2]

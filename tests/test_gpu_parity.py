@@ -119,6 +119,27 @@ def test_color_network_forward_backward(precision):
         assert rel_err(nrm_g.grad, g_o[-2]) < 2e-4 and rel_err(feat_g.grad, g_o[-1]) < 2e-4
 
 
+def test_camera_rays_kernel():
+    """get_camera_params with the pose and with the identity, one launch."""
+    from oracle import monosdf_oracle as mo
+    from monosdf_amd import ops
+    g = torch.Generator().manual_seed(11)
+    for n in (1, 63, 1024 + 5):
+        uv = torch.rand(1, n, 2, generator=g) * 384
+        K = torch.eye(4)[None].clone()
+        K[0, 0, 0], K[0, 1, 1], K[0, 0, 2], K[0, 1, 2], K[0, 0, 1] = 300.0, 310.0, 190.5, 188.25, 0.7
+        q, _ = torch.linalg.qr(torch.randn(3, 3, generator=g))
+        pose = torch.eye(4)[None].clone()
+        pose[0, :3, :3], pose[0, :3, 3] = q, torch.tensor([0.3, -0.2, 0.5])
+        d_o, c_o = mo.camera_rays(uv, pose, K)
+        dc_o, _ = mo.camera_rays(uv, torch.eye(4)[None], K)
+        d, dc, c = ops.camera_rays(uv[0].cuda(), pose[0].cuda(), K[0].cuda())
+        assert rel_err(d, d_o[0]) < 1e-6 and rel_err(dc, dc_o[0]) < 1e-6
+        assert torch.equal(c.cpu(), c_o.expand(n, 3))
+    with pytest.raises(NotImplementedError):
+        ops.camera_rays(uv[0].cuda(), torch.zeros(7).cuda(), K[0].cuda())
+
+
 def test_compositor_forward_backward():
     from oracle import monosdf_oracle as mo
     from monosdf_amd import ops
