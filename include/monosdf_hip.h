@@ -228,6 +228,31 @@ typedef struct {
 } msdf_probe_loss_args_t;
 int msdf_probe_loss(const msdf_probe_loss_args_t* args, void* stream);
 
+/* ---- MonoSDFLoss (reference: model/loss.py:180-311 with loss.py:29-87,156-171), pixel-batch mode,
+ * L1 colour loss.  One launch returns the seven scalars of the reference's output dict and the gradients of
+ * `loss` with respect to every model output.  The decay factor (loss.py:291-296) is folded into w_depth /
+ * w_nl1 / w_ncos by the caller. */
+typedef struct {
+  const float* rgb;          /* [N,3] rgb_values */
+  const float* depth;        /* [N]   depth_values */
+  const float* normal;       /* [N,3] normal_map */
+  const float* sdf;          /* [N,S] sdf of the ray samples (foreground mask: sign change along the ray) */
+  const float* grad_theta;   /* [E,3] or NULL (no eikonal / smoothness terms) */
+  const float* grad_nei;     /* [E,3] or NULL */
+  const float* rgb_gt;       /* [N,3] */
+  const float* depth_gt;     /* [N]   monocular depth cue */
+  const float* normal_gt;    /* [N,3] monocular normal cue */
+  const float* mask_gt;      /* [N]   > 0.5 = valid pixel */
+  int32_t N, S, E;
+  int32_t gamma;             /* if_gamma_loss */
+  int32_t scale_invariant;   /* if_scale_invariant_depth */
+  float w_eik, w_smooth, w_depth, w_nl1, w_ncos;
+  float* mask;               /* [N] scratch / output: the combined mask as 0 / 1 */
+  float* out;                /* [8]: loss, rgb_loss, eikonal_loss, smooth_loss, depth_loss, normal_l1, normal_cos, sum(mask) */
+  float* g_rgb; float* g_depth; float* g_normal; float* g_theta; float* g_nei;   /* d loss / d input */
+} msdf_monosdf_loss_args_t;
+int msdf_monosdf_loss(const msdf_monosdf_loss_args_t* args, void* stream);
+
 /* ---- error-bounded sampler (reference: model/ray_sampler.py:48-83, 110-272) ---- */
 typedef struct {
   const float* ray_o;        /* [N,3] */

@@ -106,6 +106,14 @@ class ProbeLossArgs(C.Structure):
                 ('g_rgb', _P), ('g_nrm', _P), ('g_depth', _P), ('g_g1', _P), ('g_g2', _P), ('partial', _P)]
 
 
+class MonoSdfLossArgs(C.Structure):
+    _fields_ = [(n, _P) for n in ('rgb', 'depth', 'normal', 'sdf', 'grad_theta', 'grad_nei', 'rgb_gt', 'depth_gt',
+                                  'normal_gt', 'mask_gt')] + \
+               [(n, C.c_int32) for n in ('N', 'S', 'E', 'gamma', 'scale_invariant')] + \
+               [(n, C.c_float) for n in ('w_eik', 'w_smooth', 'w_depth', 'w_nl1', 'w_ncos')] + \
+               [(n, _P) for n in ('mask', 'out', 'g_rgb', 'g_depth', 'g_normal', 'g_theta', 'g_nei')]
+
+
 class SamplerArgs(C.Structure):
     _fields_ = [('ray_o', _P), ('ray_d', _P), ('N', C.c_int32), ('M', C.c_int32), ('m_max', C.c_int32),
                 ('n_eval', C.c_int32), ('n_final', C.c_int32), ('n_extra', C.c_int32),
@@ -139,6 +147,7 @@ _SIGNATURES = {
     'msdf_color_backward': [C.POINTER(Plan), C.POINTER(ColorBwdArgs), _P],
     'msdf_wgrad': [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, _P],
     'msdf_camera_rays': [_P, _P, _P, C.c_int, _P, _P, _P, _P],
+    'msdf_monosdf_loss': [C.POINTER(MonoSdfLossArgs), _P],
     'msdf_reduce': [_P, C.c_int, _P, _P, _P, _P],
     'msdf_composite_forward': [C.POINTER(CompositeArgs), _P],
     'msdf_composite_backward': [C.POINTER(CompositeBwdArgs), _P],

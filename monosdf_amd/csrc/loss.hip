@@ -3,8 +3,7 @@
 //   n_i = g_i / (|g_i| + 1e-5),  g1 = grad_theta, g2 = grad_theta_nei.
 // Every term is a mean of per-row functions, so each row's gradient is local; the loss value is
 // reduced per block and summed on the host side of the stream (deterministic).
-// The same structure (per-ray terms + eikonal/smooth terms on the SDF gradients) is what the reference's
-// MonoSDFLoss has (code/model/loss.py:180-311); porting that loss is the "next" row 8(f)-2.
+// msdf_monosdf_loss below is the reference's training loss.
 #include "common.h"
 
 __device__ __forceinline__ float sgnf(const float v) { return (v > 0.f) ? 1.f : (v < 0.f) ? -1.f : 0.f; }
@@ -61,6 +60,175 @@ msdf_probe_loss_k(const msdf_probe_loss_args_t a) {
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
   __syncthreads();
   if (threadIdx.x == 0) a.partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// ---------------------------------------------------------------------------
+// MonoSDFLoss (reference: code/model/loss.py:180-311, pixel-batch mode, rgb_loss = torch.nn.L1Loss) with the
+// gradients of `loss` with respect to every model output, in ONE launch of ONE workgroup (the loss couples
+// all rays of the batch through the 2x2 scale/shift solve, and the batch is ~1k rays).
+//
+//   pass 1 (wave per ray)   foreground mask: the ray's sdf samples change sign  (loss.py:277)
+//   pass 2 (thread per ray) masked sums of the scale/shift system (loss.py:29-49), L1 colour term (+gamma,
+//                            loss.py:209-220), normal L1 / cosine terms (loss.py:245-250) and their gradients;
+//          (thread per pt)  eikonal (loss.py:222-224) and smoothness (loss.py:226-234) terms + gradients
+//   pass 3 (thread per ray) depth residuals with the solved scale / shift (loss.py:156-171, 75-87) + gradient.
+// d(depth term)/d(prediction) through scale and shift vanishes identically (they minimise the same masked
+// squared residual), so the gradient is m * res * scale / M; the fixtures recorded from the reference's
+// autograd confirm it to rounding.  All reductions are fixed-order (thread-serial, wave butterfly, 16 waves).
+// ---------------------------------------------------------------------------
+#define ML_THREADS 1024
+#define ML_NSUM 10
+
+__device__ __forceinline__ float ml_gamma2(const float x) {
+  return (x <= 0.0031308f) ? 12.92f * x : 1.055f * __powf(x, 1.0f / 2.4f) - 0.055f;
+}
+__device__ __forceinline__ float ml_gamma2_grad(const float x) {
+  return (x <= 0.0031308f) ? 12.92f : (1.055f / 2.4f) * __powf(x, 1.0f / 2.4f - 1.0f);
+}
+
+// sums[k] over the whole workgroup, result broadcast to every thread through `red`
+template <int K>
+__device__ __forceinline__ void ml_block_sum(float (&v)[K], float* red) {
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v[k] += __shfl_xor(v[k], d, 64);
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();                                   // previous users of `red` are done
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int k = 0; k < K; ++k) red[wave * K + k] = v[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    float s = 0.f;
+    for (int w = 0; w < ML_THREADS / 64; ++w) s += red[w * K + k];
+    v[k] = s;
+  }
+}
+
+__global__ void __launch_bounds__(ML_THREADS)
+msdf_monosdf_loss_k(const msdf_monosdf_loss_args_t a) {
+  __shared__ float red[(ML_THREADS / 64) * ML_NSUM];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = a.N, E = a.E;
+  // ---- pass 1: foreground mask (and the ground-truth mask), one wave per ray
+  for (int r = wave; r < N; r += ML_THREADS / 64) {
+    bool pos = false, neg = false;
+    for (int j = lane; j < a.S; j += 64) {
+      const float v = a.sdf[(size_t)r * a.S + j];
+      pos |= v > 0.f;
+      neg |= v < 0.f;
+    }
+    const bool fg = (__ballot(pos) != 0ull) && (__ballot(neg) != 0ull);
+    if (lane == 0) a.mask[r] = (fg && a.mask_gt[r] > 0.5f) ? 1.0f : 0.0f;
+  }
+  __threadfence_block();
+  __syncthreads();
+  // ---- pass 2
+  float sums[ML_NSUM];
+#pragma unroll
+  for (int k = 0; k < ML_NSUM; ++k) sums[k] = 0.f;
+  const float inv3n = 1.0f / (3.0f * N), invn = 1.0f / N;
+  for (int r = tid; r < N; r += ML_THREADS) {
+    const float m = a.mask[r];
+    const float p = a.depth[r];
+    const float t = a.scale_invariant ? a.depth_gt[r] * 50.0f + 0.5f : a.depth_gt[r];
+    sums[0] += m * p * p;
+    sums[1] += m * p;
+    sums[2] += m;
+    sums[3] += m * p * t;
+    sums[4] += m * t;
+    float nv[3], ng[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float x = a.rgb[(size_t)r * 3 + c], y = a.rgb_gt[(size_t)r * 3 + c];
+      const float fx = a.gamma ? ml_gamma2(x) : x, fy = a.gamma ? ml_gamma2(y) : y;
+      sums[5] += fabsf(fx - fy);
+      a.g_rgb[(size_t)r * 3 + c] = sgnf(fx - fy) * (a.gamma ? ml_gamma2_grad(x) : 1.0f) * inv3n;
+      nv[c] = a.normal[(size_t)r * 3 + c] * m;
+      ng[c] = a.normal_gt[(size_t)r * 3 + c];
+    }
+    // F.normalize: v / max(|v|, 1e-12)
+    const float lv = fmaxf(sqrtf(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]), 1e-12f);
+    const float lg = fmaxf(sqrtf(ng[0] * ng[0] + ng[1] * ng[1] + ng[2] * ng[2]), 1e-12f);
+    float dn[3], dot = 0.f, adot = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      nv[c] /= lv;
+      ng[c] /= lg;
+      sums[6] += fabsf(nv[c] - ng[c]);
+      dot += nv[c] * ng[c];
+      dn[c] = (a.w_nl1 * sgnf(nv[c] - ng[c]) - a.w_ncos * ng[c]) * invn;     // d loss / d n-hat
+      adot += nv[c] * dn[c];
+    }
+    sums[7] += 1.0f - dot;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a.g_normal[(size_t)r * 3 + c] = m * (dn[c] - nv[c] * adot) / lv;
+  }
+  if (a.grad_theta != nullptr) {
+    const float inve = 1.0f / E;
+    for (int i = tid; i < E; i += ML_THREADS) {
+      const float* g1 = a.grad_theta + (size_t)i * 3;
+      const float* g2 = a.grad_nei + (size_t)i * 3;
+      const float l1 = sqrtf(g1[0] * g1[0] + g1[1] * g1[1] + g1[2] * g1[2]);
+      const float l2 = sqrtf(g2[0] * g2[0] + g2[1] * g2[1] + g2[2] * g2[2]);
+      const float e = l1 - 1.0f;
+      sums[8] += e * e;
+      const float d1 = l1 + 1e-5f, d2 = l2 + 1e-5f;
+      float d[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) d[c] = g1[c] / d1 - g2[c] / d2;
+      const float sn = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+      sums[9] += sn;
+      const float k = (sn > 0.f) ? a.w_smooth * inve / sn : 0.f;
+      const float ug1 = d[0] * g1[0] + d[1] * g1[1] + d[2] * g1[2];
+      const float ug2 = d[0] * g2[0] + d[1] * g2[1] + d[2] * g2[2];
+      const float eik = (l1 > 0.f) ? a.w_eik * 2.0f * e * inve / l1 : 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float j1 = d[c] / d1 - ((l1 > 0.f) ? g1[c] * ug1 / (l1 * d1 * d1) : 0.f);
+        const float j2 = d[c] / d2 - ((l2 > 0.f) ? g2[c] * ug2 / (l2 * d2 * d2) : 0.f);
+        a.g_theta[(size_t)i * 3 + c] = eik * g1[c] + k * j1;
+        a.g_nei[(size_t)i * 3 + c] = -k * j2;
+      }
+    }
+  }
+  ml_block_sum<ML_NSUM>(sums, red);
+  // ---- scale / shift (compute_scale_and_shift_1D) and pass 3
+  float scale = 1.0f, shift = 0.0f;
+  if (a.scale_invariant) {
+    const float det = sums[0] * sums[2] - sums[1] * sums[1];
+    scale = (det != 0.f) ? (sums[2] * sums[3] - sums[1] * sums[4]) / det : 0.f;
+    shift = (det != 0.f) ? (-sums[1] * sums[3] + sums[0] * sums[4]) / det : 0.f;
+  }
+  const float M = sums[2];
+  float dsum[1] = {0.f};
+  for (int r = tid; r < N; r += ML_THREADS) {
+    const float m = a.mask[r];
+    const float t = a.scale_invariant ? a.depth_gt[r] * 50.0f + 0.5f : a.depth_gt[r];
+    const float res = scale * a.depth[r] + shift - t;
+    dsum[0] += m * res * res;
+    a.g_depth[r] = (M > 0.f) ? a.w_depth * m * res * scale / M : 0.f;
+  }
+  ml_block_sum<1>(dsum, red);
+  if (tid == 0) {
+    const float rgb_l = sums[5] * inv3n, nl1 = sums[6] * invn, ncos = sums[7] * invn;
+    const float eik = (a.grad_theta != nullptr) ? sums[8] / E : 0.f;
+    const float smooth = (a.grad_theta != nullptr) ? sums[9] / E : 0.f;
+    const float dl = (M > 0.f) ? dsum[0] / (2.0f * M) : 0.f;
+    a.out[0] = rgb_l + a.w_eik * eik + a.w_smooth * smooth + a.w_depth * dl + a.w_nl1 * nl1 + a.w_ncos * ncos;
+    a.out[1] = rgb_l; a.out[2] = eik; a.out[3] = smooth; a.out[4] = dl; a.out[5] = nl1; a.out[6] = ncos;
+    a.out[7] = M;
+  }
+}
+
+extern "C" int msdf_monosdf_loss(const msdf_monosdf_loss_args_t* a, void* stream) {
+  if (a == nullptr || a->N < 1 || a->S < 1 || a->E < 0) return MSDF_ERR_ARG;
+  if ((a->grad_theta == nullptr) != (a->grad_nei == nullptr)) return MSDF_ERR_ARG;
+  if (a->grad_theta != nullptr && a->E < 1) return MSDF_ERR_ARG;
+  msdf_monosdf_loss_k<<<1, ML_THREADS, 0, (hipStream_t)stream>>>(*a);
+  return msdf_check_launch();
 }
 
 extern "C" int msdf_probe_loss(const msdf_probe_loss_args_t* a, void* stream) {

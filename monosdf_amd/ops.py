@@ -623,6 +623,62 @@ def probe_loss(out, w_normal=0.05, w_depth=0.1, w_eik=0.05, w_smooth=0.005):
                                    out['grad_theta_nei'], w_normal, w_depth, w_eik, w_smooth)
 
 
+class MonoSdfLossFunction(torch.autograd.Function):
+    """(rgb_values, depth_values, normal_map, grad_theta, grad_theta_nei | data) -> [8] scalars of MonoSDFLoss.
+    Element 0 is `loss`; gradients flow from it only (the other entries are the reference's logging scalars)."""
+
+    @staticmethod
+    def forward(ctx, rgb, depth, normal, g1, g2, sdf, rgb_gt, depth_gt, normal_gt, mask_gt, weights, gamma,
+                scale_invariant):
+        rgb, normal = _need_cuda(rgb.detach(), 'rgb_values'), _need_cuda(normal.detach(), 'normal_map')
+        ctx.depth_shape = depth.shape
+        depth = _need_cuda(depth.detach(), 'depth_values').reshape(-1)
+        sdf = _need_cuda(sdf.detach(), 'sdf')
+        N = rgb.shape[0]
+        sdf = sdf.reshape(N, -1)
+        has_eik = g1 is not None
+        if has_eik:
+            g1, g2 = _need_cuda(g1.detach(), 'grad_theta'), _need_cuda(g2.detach(), 'grad_theta_nei')
+            if g1.shape != g2.shape:
+                raise RuntimeError('monosdf_amd: grad_theta and grad_theta_nei must have the same shape')
+        dev = rgb.device
+        data = [_need_cuda(t.detach().to(dev).float(), n).reshape(-1)
+                for t, n in ((rgb_gt, 'rgb ground truth'), (depth_gt, 'depth cue'), (normal_gt, 'normal cue'),
+                             (mask_gt, 'mask'))]
+        if data[0].numel() != 3 * N or data[1].numel() != N or data[2].numel() != 3 * N or data[3].numel() != N:
+            raise RuntimeError('monosdf_amd: ground-truth tensors do not match the %d rays of the batch' % N)
+        out = torch.empty(8, device=dev, dtype=torch.float32)
+        mask = torch.empty(N, device=dev, dtype=torch.float32)
+        grads = [torch.empty_like(rgb), torch.empty_like(depth), torch.empty_like(normal)]
+        if has_eik:
+            grads += [torch.empty_like(g1), torch.empty_like(g2)]
+        a = _lib.MonoSdfLossArgs()
+        a.rgb, a.depth, a.normal, a.sdf = rgb.data_ptr(), depth.data_ptr(), normal.data_ptr(), sdf.data_ptr()
+        a.grad_theta = g1.data_ptr() if has_eik else None
+        a.grad_nei = g2.data_ptr() if has_eik else None
+        a.rgb_gt, a.depth_gt, a.normal_gt, a.mask_gt = [t.data_ptr() for t in data]
+        a.N, a.S, a.E = N, sdf.shape[1], (g1.shape[0] if has_eik else 0)
+        a.gamma, a.scale_invariant = int(bool(gamma)), int(bool(scale_invariant))
+        a.w_eik, a.w_smooth, a.w_depth, a.w_nl1, a.w_ncos = [float(w) for w in weights]
+        a.mask, a.out = mask.data_ptr(), out.data_ptr()
+        a.g_rgb, a.g_depth, a.g_normal = [t.data_ptr() for t in grads[:3]]
+        a.g_theta = grads[3].data_ptr() if has_eik else None
+        a.g_nei = grads[4].data_ptr() if has_eik else None
+        _lib.call('msdf_monosdf_loss', C.byref(a), _lib.stream_ptr())
+        ctx.has_eik = has_eik
+        ctx.save_for_backward(*grads)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_out):
+        grads = ctx.saved_tensors
+        g = g_out[0]
+        res = [grads[0] * g, (grads[1] * g).reshape(ctx.depth_shape), grads[2] * g]
+        res += [grads[3] * g, grads[4] * g] if ctx.has_eik else [None, None]
+        return tuple(res) + (None,) * 8
+
+
 # ---------------------------------------------------------------------------
 # ray generation (image-mode inputs)
 # ---------------------------------------------------------------------------

@@ -58,4 +58,5 @@ def rel_err(a, b):
     return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
 
 
-ALL_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith('.npz') and f != 'stages.npz')
+ALL_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN)
+                   if f.endswith('.npz') and f != 'stages.npz' and not f.startswith('loss_'))

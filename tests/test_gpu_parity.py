@@ -140,6 +140,27 @@ def test_camera_rays_kernel():
         ops.camera_rays(uv[0].cuda(), torch.zeros(7).cuda(), K[0].cuda())
 
 
+def test_monosdf_loss_against_reference_fixtures():
+    """the fused training loss against values + gradients recorded from the reference class."""
+    from test_loss_oracle import GOLDEN, GRAD_KEYS, SCALARS, load_case
+    from monosdf_amd.model.loss import MonoSDFLoss
+    assert len(GOLDEN) == 5
+    for path in GOLDEN:
+        out, gt, ref, grads, kw, step = load_case(path)
+        leaves = {k: (v.cuda().requires_grad_(True) if k in GRAD_KEYS else v.cuda()) for k, v in out.items()}
+        mod = MonoSDFLoss(rgb_loss='torch.nn.L1Loss', **kw)
+        mod.step = step
+        res = mod(leaves, gt, if_pixel_input=True)            # ground truth arrives on the host, as from the loader
+        for k in SCALARS:
+            assert abs(res[k].item() - ref[k]) <= 1e-5 * max(1.0, abs(ref[k])), (path, k, res[k].item(), ref[k])
+        res['loss'].backward()
+        for k in GRAD_KEYS:
+            assert rel_err(leaves[k].grad, grads[k]) < TOL, (path, k, rel_err(leaves[k].grad, grads[k]))
+        assert mod.step == step + 1
+    with pytest.raises(AssertionError):
+        mod(leaves, gt, if_pixel_input=False)
+
+
 def test_compositor_forward_backward():
     from oracle import monosdf_oracle as mo
     from monosdf_amd import ops

@@ -44,7 +44,7 @@ def test_struct_sizes_match_header():
              'msdf_color_fwd_args_t': _lib.ColorFwdArgs, 'msdf_color_bwd_args_t': _lib.ColorBwdArgs,
              'msdf_composite_args_t': _lib.CompositeArgs, 'msdf_composite_bwd_args_t': _lib.CompositeBwdArgs,
              'msdf_sampler_args_t': _lib.SamplerArgs, 'msdf_wn_layer_t': _lib.WnLayer,
-             'msdf_probe_loss_args_t': _lib.ProbeLossArgs}
+             'msdf_probe_loss_args_t': _lib.ProbeLossArgs, 'msdf_monosdf_loss_args_t': _lib.MonoSdfLossArgs}
     src = '#include <stdio.h>\n#include "monosdf_hip.h"\nint main(){' + ''.join(
         'printf("%s %%zu\\n", sizeof(%s));' % (n, n) for n in names) + 'return 0;}'
     with tempfile.TemporaryDirectory() as d:
