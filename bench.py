@@ -199,7 +199,7 @@ def main():
             kern[name] = {'launches_per_step': len(ms) / args.steps, 'avg_ms': float(np.mean(ms)),
                           'ms_per_step': float(np.sum(ms)) / args.steps}
         plan = model.implicit_network._fused(device).mp.plan
-        return dict(dt=dt, kern=kern, rounds=rounds, loss=float(loss.item()),
+        return dict(dt=dt, kern=kern, rounds=rounds, loss=float(loss.item()), precision=precision,
                     slots=(plan.hsum, plan.qsum, plan.absum))
 
     def mlp_rooflines(m):
@@ -224,9 +224,11 @@ def main():
         mf = {'bound': 'mfma', 'kernel': dom, 'achieved': flops[dom] / t / 1e12, 'peak': F32_MFMA_PEAK_TFLOPS,
               'unit': 'TFLOP/s', 'frac': flops[dom] / t / 1e12 / F32_MFMA_PEAK_TFLOPS, 'traffic': None,
               'avg_kernel_ms': kern[dom]['avg_ms']}
-        if dom == 'msdf_sdf_backward':
-            # rocprofv3 FETCH_SIZE(x2)+WRITE_SIZE of this kernel, profiles/r01_v3_pmc_summary.json (same data movement)
-            mf['traffic'] = 6.55e9
+        # rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE per launch of the same command,
+        # profiles/r01_v5_pmc_{fp32,bf16x3}.json (separate passes; the kernels' data movement is fixed by P)
+        measured = {'fp32': {'msdf_sdf_backward': 6.556e9, 'msdf_sdf_fwd_grad': 2.939e9, 'msdf_sdf_forward': 1.85e7},
+                    'bf16x3': {'msdf_sdf_backward': 6.509e9, 'msdf_sdf_fwd_grad': 3.014e9, 'msdf_sdf_forward': 1.106e8}}
+        mf['traffic'] = measured[m['precision']].get(dom)
         hb = None
         if dom in hbm:
             hb = {'bound': 'hbm', 'kernel': dom, 'achieved': hbm[dom] / t / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
