@@ -1,0 +1,162 @@
+"""Full-size checks (BASELINE.json configs[1] / configs[2] shapes: 1024 rays x 98 samples, 8x256 SDF MLP; 16x2
+hash grid at 104,448 points) through size-independent properties -- the oracle takes minutes at this size:
+partition of unity of the compositing weights, composites recomputed from the per-sample outputs,
+run-to-run bitwise reproducibility, a central finite difference of the loss against the analytic parameter
+gradient, agreement of the two matrix cores, linearity / adjointness of the hash-grid kernels."""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench                                    # noqa: E402  (model_conf / make_rays of the bench workload)
+
+pytestmark = pytest.mark.gpu
+N = bench.N_RAYS
+
+
+def _model(precision, seed=0):
+    from monosdf_amd.model.network import MonoSDFNetwork
+    torch.manual_seed(seed)
+    return MonoSDFNetwork(bench.model_conf()).cuda().train().set_precision(precision)
+
+
+def _step(model, rays, seed=7):
+    from monosdf_amd import ops
+    torch.manual_seed(seed)                    # the same six random draws every call
+    model.zero_grad(set_to_none=True)
+    out = model(rays, torch.arange(N, device='cuda'), if_pixel_input=True)
+    loss = ops.probe_loss(out)
+    loss.backward()
+    return out, loss
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+def test_fullsize_compositing_identities_and_reproducibility(precision):
+    model = _model(precision)
+    rays = bench.make_rays(N, 1, 'cuda')
+    out, loss = _step(model, rays)
+    w, z = out['weights'], out['z_vals']
+    assert w.shape == (N, 98) and out['rgb'].shape == (N, 98, 3)
+    assert (w >= 0).all()
+    assert (w.sum(1) - 1).abs().max().item() < 2e-5            # last interval is 1e10: the weights sum to one
+    rgb_values = (w.unsqueeze(-1) * out['rgb']).sum(1)
+    assert (rgb_values - out['rgb_values']).abs().max().item() < 2e-6
+    depth = (w * z).sum(1, keepdim=True) / (w.sum(1, keepdim=True) + 1e-8) * rays['ray_dirs_tmp'][:, 2:]
+    assert (depth - out['depth_values']).abs().max().item() < 2e-5
+    assert (out['depth_vals'] - z * rays['ray_dirs_tmp'][:, 2:]).abs().max().item() == 0.0
+    g1 = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    out2, loss2 = _step(model, rays)
+    assert loss.item() == loss2.item()
+    for k in ('rgb_values', 'depth_values', 'normal_map', 'sdf', 'weights', 'grad_theta'):
+        assert torch.equal(out[k], out2[k]), k                 # no float atomics on this path: bitwise reproducible
+    for n, p in model.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(p.grad, g1[n]), n
+
+
+def _central_difference(p, d, eps, value_fn):
+    vals = []
+    for s in (+1.0, -1.0):
+        with torch.no_grad():
+            p.add_(s * eps * d)
+            vals.append(value_fn())
+            p.sub_(s * eps * d)
+    return (vals[0] - vals[1]) / (2 * eps)
+
+
+def test_fullsize_directional_derivative():
+    """(L(theta + e d) - L(theta - e d)) / 2e  vs  <grad L, d>.
+    Colour-network parameters through the whole step (they do not move the samples); SDF-network parameters
+    through get_outputs on fixed points (first- and second-order paths) -- in the full step the sampler places
+    the samples from the SDF under no_grad, as the reference does, so a finite difference would see that too."""
+    from monosdf_amd import ops
+    model = _model('fp32')
+    rays = bench.make_rays(N, 1, 'cuda')
+    _step(model, rays)
+    params = dict(model.named_parameters())
+    idx = torch.arange(N, device='cuda')
+
+    def step_loss():
+        torch.manual_seed(7)
+        return ops.probe_loss(model(rays, idx, if_pixel_input=True)).item()
+
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    for name in ('rendering_network.lin1.bias', 'rendering_network.lin0.weight_g'):
+        p = params[name]
+        d = torch.randn(p.shape, device='cuda', generator=gen)
+        d /= d.norm()
+        analytic = (p.grad * d).sum().item()
+        numeric = _central_difference(p, d, 2e-3, step_loss)
+        assert abs(numeric - analytic) <= 0.02 * abs(analytic) + 2e-6, (name, numeric, analytic)
+
+    P = N * 102
+    x = (torch.rand(P, 3, device='cuda', generator=gen) * 2 - 1) * 0.9
+    ca = torch.randn(P, 1, device='cuda', generator=gen) / P
+    cb = torch.randn(P, 256, device='cuda', generator=gen) * 0.1 / P
+    cc = torch.randn(P, 3, device='cuda', generator=gen) / P
+
+    def probe(with_grad):
+        # the gradient term uses gradient_sdf (unclamped sdf, network.py:98-109): get_outputs' min(sdf, sphere)
+        # makes d sdf/dx JUMP when a point changes sides, which a few of the 104,448 points do under any
+        # finite step (measured: each such point moves the difference quotient by O(1)/(P eps))
+        sdf, feat, _ = model.implicit_network.get_outputs(x)
+        grad = model.implicit_network.gradient_sdf(x)
+        # fp64 sums: the fp32 reduction noise of 27M terms would be as large as the finite difference
+        return ((ca.double() * sdf.double()).sum() + (cb.double() * feat.double()).sum() +
+                (cc.double() * grad.double()).sum())
+
+    model.zero_grad(set_to_none=True)
+    probe(True).backward()
+    for name in ('implicit_network.lin3.bias', 'implicit_network.lin6.weight_g', 'implicit_network.lin0.weight_v'):
+        p = params[name]
+        d = p.grad / p.grad.norm()                      # steepest direction: the largest signal per unit step
+        analytic = (p.grad * d).sum().item()
+        # 1e-4: Softplus(beta=100) bends over ~1e-2 of pre-activation; steps of 1e-3 / 3e-4 along the steepest
+        # direction already show its curvature (70 % / 4 % off), the fp64 probe keeps 1e-4 above the noise
+        numeric = _central_difference(p, d, 1e-4, lambda: probe(False).item())
+        assert abs(numeric - analytic) <= 0.02 * abs(analytic) + 1e-7, (name, numeric, analytic)
+
+
+def test_fullsize_matrix_cores_agree():
+    rays = bench.make_rays(N, 1, 'cuda')
+    res = {}
+    for precision in ('fp32', 'bf16x3'):
+        model = _model(precision)
+        out, loss = _step(model, rays)
+        res[precision] = (out, loss.item(), {n: p.grad.clone() for n, p in model.named_parameters()
+                                             if p.grad is not None})
+    (o32, l32, g32), (o16, l16, g16) = res['fp32'], res['bf16x3']
+    assert abs(l32 - l16) <= 1e-4 * max(1.0, abs(l32))
+    rel = lambda a, b: ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+    for k in ('rgb_values', 'depth_values', 'normal_map', 'grad_theta'):
+        assert rel(o16[k], o32[k]) < 5e-4, (k, rel(o16[k], o32[k]))      # sampler tolerance of test_gpu_parity
+    for n in g32:
+        assert rel(g16[n], g32[n]) < 2e-3, (n, rel(g16[n], g32[n]))
+
+
+def test_fullsize_hash_grid_linearity_and_adjointness():
+    """forward is linear in the table; backward (LDS path for the two coarsest levels + atomics) is its adjoint."""
+    from monosdf_amd.hashencoder.hashgrid import HashEncoder
+    enc = HashEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19,
+                      desired_resolution=2048).cuda()
+    B = N * 102
+    g = torch.Generator(device='cuda').manual_seed(5)
+    x = torch.rand(B, 3, device='cuda', generator=g) * 2 - 1
+    with torch.no_grad():
+        enc.embeddings.copy_(torch.randn(enc.embeddings.shape, device='cuda', generator=g) * 0.1)
+    y = enc(x)
+    g1 = torch.randn(y.shape, device='cuda', generator=g)
+    g2 = torch.randn(y.shape, device='cuda', generator=g)
+    ga, = torch.autograd.grad(y, enc.embeddings, g1, retain_graph=True)
+    gb, = torch.autograd.grad(y, enc.embeddings, g2, retain_graph=True)
+    gab, = torch.autograd.grad(y, enc.embeddings, g1 + g2)
+    scale = gab.abs().max().item()
+    assert (ga + gb - gab).abs().max().item() < 1e-4 * scale              # linearity (atomics: order noise only)
+    lhs = (y.double() * g1.double()).sum().item()                        # <E(theta), g>
+    rhs = (enc.embeddings.double() * ga.double()).sum().item()          # <theta, E^T g>
+    assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), 1.0), (lhs, rhs)
+    # coarsest levels: every one of their entries receives gradient from ~100k points
+    n0 = int(enc.offsets[2].item())
+    assert (ga[:n0].abs().sum(1) > 0).float().mean().item() > 0.5
