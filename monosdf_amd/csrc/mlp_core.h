@@ -63,50 +63,34 @@ __device__ __forceinline__ void chunk_issue(const v4f* __restrict__ src, v4f* ds
 // All 256 threads of the workgroup must call this together (it contains barriers).
 // `lds` points at 2 * LDS_BUF_F4 float4; on return every wave has passed a barrier
 // after its last LDS read, so the caller may start the next gemm immediately.
-template <int KT_T>
+struct NoTail {
+  __device__ __forceinline__ void operator()() const {}
+};
+
+// tail(): called once, after the LAST weight chunk has been waited for and before its matrix products -- the
+// place to issue global loads the caller's epilogue will need: no later s_waitcnt vmcnt inside the GEMM waits
+// for them, and the chunk's ~2 us of MFMAs cover their latency.
+template <int KT_T, class Tail>
 __device__ __forceinline__ void gemm_tiles(v4f (&acc)[MT], const v4f (&in)[MT], const int OT, const int k_rt,
-                                           const v4f* __restrict__ wsrc, v4f* lds) {
+                                           const v4f* __restrict__ wsrc, v4f* lds, const Tail& tail) {
   constexpr bool DYN = (KT_T == 0);
   constexpr int KMAX = DYN ? MT : KT_T;
   const int K = DYN ? k_rt : KT_T;
   const int ch_f4 = CHUNK_OT * K * 64;
   const int lane = threadIdx.x & 63;
   const int nchunks = (OT + CHUNK_OT - 1) / CHUNK_OT;
-#if MSDF_USE_GLDS
-  chunk_issue<CHUNK_OT * KMAX>(wsrc, lds, ch_f4);
-#else
-  constexpr int PER_T = (CHUNK_OT * KMAX * 64 + MLP_THREADS - 1) / MLP_THREADS;
-  const int tid = threadIdx.x;
-  v4f stage[PER_T];
-#pragma unroll
-  for (int i = 0; i < PER_T; ++i) {
-    const int idx = tid + i * MLP_THREADS;
-    if (idx < ch_f4) stage[i] = wsrc[idx];
-  }
-#pragma unroll
-  for (int i = 0; i < PER_T; ++i) {
-    const int idx = tid + i * MLP_THREADS;
-    if (idx < ch_f4) lds[idx] = stage[i];
-  }
-#endif
+  // Chunks are consumed from the LAST pair of out tiles down to the first, so that the final chunk is always
+  // c == 0 -- a compile-time position for the tail hook (its loads are then live in that iteration only).
+  chunk_issue<CHUNK_OT * KMAX>(wsrc + (size_t)(nchunks - 1) * ch_f4, lds + ((nchunks - 1) & 1) * LDS_BUF_F4, ch_f4);
   __syncthreads();
 #pragma unroll
-  for (int c = 0; c < (MT + 1) / 2; ++c) {
+  for (int c = (MT + 1) / 2 - 1; c >= 0; --c) {
     if (c < nchunks) {
       const int buf = c & 1;
-      const bool has_next = (c + 1 < nchunks);
-      if (has_next) {
-        const v4f* src = wsrc + (size_t)(c + 1) * ch_f4;
-#if MSDF_USE_GLDS
-        chunk_issue<CHUNK_OT * KMAX>(src, lds + (buf ^ 1) * LDS_BUF_F4, ch_f4);
-#else
-#pragma unroll
-        for (int i = 0; i < PER_T; ++i) {
-          const int idx = tid + i * MLP_THREADS;
-          if (idx < ch_f4) stage[i] = src[idx];
-        }
-#endif
-      }
+      const bool has_next = (c > 0);
+      if (has_next)
+        chunk_issue<CHUNK_OT * KMAX>(wsrc + (size_t)(c - 1) * ch_f4, lds + (buf ^ 1) * LDS_BUF_F4, ch_f4);
+      if (c == 0) tail();
       const v4f* w0 = lds + buf * LDS_BUF_F4 + lane;
       const v4f* w1 = w0 + K * 64;
       const int o0 = 2 * c;
@@ -179,29 +163,20 @@ __device__ __forceinline__ void gemm_tiles(v4f (&acc)[MT], const v4f (&in)[MT], 
           }
         }
       }
-#if !MSDF_USE_GLDS
-      if (has_next) {
-        v4f* dst = lds + (buf ^ 1) * LDS_BUF_F4;
-#pragma unroll
-        for (int i = 0; i < PER_T; ++i) {
-          const int idx = tid + i * MLP_THREADS;
-          if (idx < ch_f4) dst[idx] = stage[i];
-        }
-      }
-#endif
       __syncthreads();
     }
   }
 }
 
 // Specialised for the K values of the 256-wide networks; anything else takes the guarded path.
+template <class Tail>
 __device__ __forceinline__ void gemm_dispatch(const int kp, v4f (&acc)[MT], const v4f (&in)[MT], const int OT,
-                                              const v4f* __restrict__ wsrc, v4f* lds) {
+                                              const v4f* __restrict__ wsrc, v4f* lds, const Tail& tail) {
   switch (kp) {
-    case 3: gemm_tiles<3>(acc, in, OT, 3, wsrc, lds); break;
-    case 16: gemm_tiles<16>(acc, in, OT, 16, wsrc, lds); break;
-    case 17: gemm_tiles<17>(acc, in, OT, 17, wsrc, lds); break;
-    default: gemm_tiles<0>(acc, in, OT, kp, wsrc, lds); break;
+    case 3: gemm_tiles<3>(acc, in, OT, 3, wsrc, lds, tail); break;
+    case 16: gemm_tiles<16>(acc, in, OT, 16, wsrc, lds, tail); break;
+    case 17: gemm_tiles<17>(acc, in, OT, 17, wsrc, lds, tail); break;
+    default: gemm_tiles<0>(acc, in, OT, kp, wsrc, lds, tail); break;
   }
 }
 
@@ -347,15 +322,17 @@ struct NoEpilogue {
 
 struct CoreF32 {
   typedef v4f wvec;                                  // one 16-byte element of the weight pack
+  static constexpr bool kTailPrefetch = true;        // gemm() honours the tail hook (see gemm_tiles)
   static __device__ __forceinline__ float softplus(const float a) {
     float h, s;
     softplus100(a, h, s);
     return h;
   }
-  template <class Epi>
+  template <class Epi, class Tail = NoTail>
   static __device__ __forceinline__ void gemm(const int kp, v4f (&acc)[MT], const v4f (&in)[MT], const int OT,
-                                              const wvec* __restrict__ wsrc, void* lds, const Epi& epi) {
-    gemm_dispatch(kp, acc, in, OT, wsrc, (v4f*)lds);
+                                              const wvec* __restrict__ wsrc, void* lds, const Epi& epi,
+                                              const Tail& tail = Tail()) {
+    gemm_dispatch(kp, acc, in, OT, wsrc, (v4f*)lds, tail);
 #pragma unroll
     for (int t = 0; t < MT; ++t)
       if (t < OT) epi(t, acc[t]);

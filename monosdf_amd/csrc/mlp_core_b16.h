@@ -204,11 +204,13 @@ __device__ __forceinline__ void gemm_b16_dispatch(const int kbp, v4f (&acc)[MT],
 
 struct CoreB16 {
   typedef v8bf wvec;
+  static constexpr bool kTailPrefetch = false;       // no spare registers: the tail hook is ignored
   static __device__ __forceinline__ float softplus(const float a) { return softplus100_lean(a); }
   // kbp: K blocks (32 slots) of the pack, i.e. ktp / otp of the bf16 plan
-  template <class Epi>
+  template <class Epi, class Tail = NoTail>
   static __device__ __forceinline__ void gemm(const int kbp, v4f (&acc)[MT], const v4f (&in)[MT], const int OT,
-                                              const wvec* __restrict__ wsrc, void* lds, const Epi& epi) {
+                                              const wvec* __restrict__ wsrc, void* lds, const Epi& epi,
+                                              const Tail& = Tail()) {
     B16Act act;
     b16_from_tiles(act, in);
     gemm_b16_dispatch(kbp, acc, act, OT, wsrc, (v8bf*)lds, epi);

@@ -247,6 +247,10 @@ __device__ __forceinline__ void sdf_fwd_grad_body(const msdf_plan_t& plan, const
 // ---------------------------------------------------------------------------
 typedef msdf_bw_args_t BwArgs;
 
+// H tiles of the next epilogue fetched during the last weight chunk of a product (fp32 core): as many as the
+// register file takes without spilling next to the 2 x 17 live activation tiles
+#define B_PREFETCH_TILES 8
+
 __device__ __forceinline__ void load_rbar(v4f (&rbar)[5], const msdf_plan_t& plan, const BwArgs& a,
                                           const PointCtx& c, const bool live, const float gn0, const float gn1,
                                           const float gn2) {
@@ -299,13 +303,22 @@ __device__ __forceinline__ void sdf_backward_body(const msdf_plan_t& plan, const
     for (int t = 0; t < MT; ++t)
       if (t < L.kt) *(v4f*)(Ql + 16 * t) = in[t];
     zero_tiles(acc);
-    Core::gemm(L.ktp, acc, in, L.ot, (const wvec*)a.wpack + L.wf_off, lds, NoEpilogue());
     const size_t off = (size_t)L.hpre * Pp + (size_t)c.pt * (16 * L.ot) + 4 * c.q;
+    // the epilogue's H tiles are fetched while the last weight chunk multiplies (one exposed HBM latency
+    // per layer instead of two)
+    v4f hpre[B_PREFETCH_TILES];
+    Core::gemm(L.ktp, acc, in, L.ot, (const wvec*)a.wpack + L.wf_off, lds, NoEpilogue(), [&]() {
+#pragma unroll
+      for (int t = 0; t < B_PREFETCH_TILES; ++t)
+        if (t < L.ot) hpre[t] = *(const v4f*)(a.H + off + 16 * t);
+    });
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
       v4f qn = V4ZERO;
       if (t < L.ot) {
-        const v4f h = *(const v4f*)(a.H + off + 16 * t);
+        v4f h;
+        if (Core::kTailPrefetch && t < B_PREFETCH_TILES) h = hpre[t < B_PREFETCH_TILES ? t : 0];
+        else h = *(const v4f*)(a.H + off + 16 * t);
         const v4f p = *(const v4f*)(a.PM + off + 16 * t);
         v4f tt;
 #pragma unroll
@@ -347,7 +360,18 @@ __device__ __forceinline__ void sdf_backward_body(const msdf_plan_t& plan, const
     }
   }
   zero_tiles(acc);
-  Core::gemm(LL.otp, acc, in, LL.kt, (const wvec*)a.wpack + LL.wb_off, lds, NoEpilogue());
+  // every product of this sweep fetches, during its last weight chunk, the H tiles of the epilogue that follows
+  v4f hnext[B_PREFETCH_TILES];
+  auto fetch_h = [&](const int l) {
+    const msdf_layer_t Ln = plan.layer[l];
+    const float* src = a.H + (size_t)Ln.hpre * Pp + (size_t)c.pt * (16 * Ln.ot) + 4 * c.q;
+#pragma unroll
+    for (int t = 0; t < B_PREFETCH_TILES; ++t)
+      if (t < Ln.ot) hnext[t] = *(const v4f*)(src + 16 * t);
+  };
+  Core::gemm(LL.otp, acc, in, LL.kt, (const wvec*)a.wpack + LL.wb_off, lds, NoEpilogue(), [&]() {
+    if (nl >= 2) fetch_h(nl - 2);
+  });
   v4f gin0[5];
 #pragma unroll
   for (int t = 0; t < 5; ++t) gin0[t] = V4ZERO;
@@ -359,7 +383,9 @@ __device__ __forceinline__ void sdf_backward_body(const msdf_plan_t& plan, const
     for (int t = 0; t < MT; ++t) {
       v4f ab = V4ZERO;
       if (t < L.ot) {
-        const v4f h = *(const v4f*)(a.H + off + 16 * t);
+        v4f h;
+        if (Core::kTailPrefetch && t < B_PREFETCH_TILES) h = hnext[t < B_PREFETCH_TILES ? t : 0];
+        else h = *(const v4f*)(a.H + off + 16 * t);
         const v4f tt = *(const v4f*)(a.T + off + 16 * t);
 #pragma unroll
         for (int r = 0; r < 4; ++r) ab[r] = acc[t][r] * (1.0f - one_minus_sigmoid_from_h(h[r])) + tt[r];
@@ -369,7 +395,9 @@ __device__ __forceinline__ void sdf_backward_body(const msdf_plan_t& plan, const
     }
     if (l == 0 && a.g_aux == nullptr) break;   // d loss / d x is not needed: skip the last product
     zero_tiles(acc);
-    Core::gemm(L.otp, acc, in, L.kt, (const wvec*)a.wpack + L.wb_off, lds, NoEpilogue());
+    Core::gemm(L.otp, acc, in, L.kt, (const wvec*)a.wpack + L.wb_off, lds, NoEpilogue(), [&]() {
+      if (l > 0) fetch_h(l - 1);
+    });
     if (a.g_aux != nullptr) {
       if (l == 0) gather_tiles(gin0, acc, 0, in0_tiles);
       else if (L.skip_tile >= 0) gather_tiles(gin0, acc, L.skip_tile, in0_tiles);
