@@ -36,5 +36,5 @@ def run(split_fn, label, iters=5):
 prog = planlib.balanced_program(planlib.build_sdf_wgrad, mp, P_pad)
 print('balanced: WGs', len(prog.wg_map()) // 2, sorted(set((it['weight'], it['n_splits']) for it in prog.items)))
 for PREC in (0, 1):
-    for S in (16, 32, 48, 64, 96, 128):
+    for S in (48, 56, 59, 60, 61, 64, 72, 73, 85):
         run(lambda w, S=S: S, '%s all items S=%d' % (ops.PRECISIONS[PREC], S))
