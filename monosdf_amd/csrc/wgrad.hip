@@ -15,22 +15,23 @@
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 #define WG_THREADS 512
-#define WG_NP 16                               // points per LDS stage
-#define WG_NBUF 4                              // LDS ring: 3 stages in flight behind the one being read
+#define WG_NP 32                               // points per LDS stage: one barrier per 128 MFMAs of each wave
+#define WG_NBUF 2                              // double buffered (a stage is ~8 us of matrix products)
 #define WG_TILE_F (WG_NP * 256)                // floats per operand tile
 #define WG_STAGE_F (2 * WG_TILE_F + 64)        // X tile, Y tile, v[NP] (+pad)
 #define WG_LDS_BYTES (WG_NBUF * WG_STAGE_F * 4)
-#define WG_GLDS_PER_STAGE 5                    // LDS-DMA instructions every wave issues per stage (uniform!)
+#define WG_PIECES (WG_NP * 256 / 4 / 64 / 8)    // 1 KB LDS-DMA pieces of one operand tile per wave: 4
+#define WG_GLDS_PER_STAGE (2 * WG_PIECES + 1)  // LDS-DMA instructions every wave issues per stage (uniform!)
 
-// Copy [WG_NP x w] (row pitch ld) into a dense LDS image with exactly TWO 1 KB LDS-DMA pieces per wave;
+// Copy [WG_NP x w] (row pitch ld) into a dense LDS image with exactly WG_PIECES 1 KB LDS-DMA pieces per wave;
 // a wave whose piece index runs past the tile re-copies the last piece (same bytes, same place), which
 // keeps the per-wave instruction count uniform so that a counted s_waitcnt vmcnt(N) is exact.
 __device__ __forceinline__ void wg_issue_tile(const float* __restrict__ src, const int ld, const int w,
                                               float* dst, const int wave, const int lane) {
   const int w4 = w >> 2;
-  const int pieces = (WG_NP * w4) >> 6;        // >= 1 (w multiple of 16, NP = 16)
+  const int pieces = (WG_NP * w4) >> 6;        // >= 2 (w multiple of 16)
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < WG_PIECES; ++i) {
     const int piece = min(wave + 8 * i, pieces - 1);
     const int u = piece * 64 + lane;
     const int row = u / w4, c4 = u - row * w4;
@@ -41,29 +42,29 @@ __device__ __forceinline__ void wg_issue_tile(const float* __restrict__ src, con
 
 __device__ __forceinline__ void wg_wait_outstanding(const int stages_behind) {
   // wait until at most `stages_behind` later stages are still in flight
+  static_assert(WG_GLDS_PER_STAGE == 9 && WG_NBUF == 2, "the immediates below are WG_GLDS_PER_STAGE multiples");
   switch (stages_behind) {
     case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
   }
 }
 
-__global__ void __launch_bounds__(WG_THREADS, 2)
-msdf_wgrad_k(const msdf_wgrad_item_t* __restrict__ items, const int* __restrict__ wg_map,
-                  const float* __restrict__ ws, float* __restrict__ part, const int P_pad) {
-  extern __shared__ float lds_f[];
-  const msdf_wgrad_item_t it = items[wg_map[2 * blockIdx.x]];
-  const int split = wg_map[2 * blockIdx.x + 1];
+// NARROW is a template parameter, not a branch inside the k loop: with the branch there, the accumulators of
+// the two variants met in phi nodes and every k step copied 32 accumulator registers behind an `s_nop 15`
+// that waited out the previous MFMA (a third of the matrix pipe's time).
+template <bool NARROW>
+__device__ __forceinline__ void wgrad_body(const msdf_wgrad_item_t& it, const int split, const float* __restrict__ ws,
+                                           float* __restrict__ part, const int P_pad, float* lds_f) {
   const int n_splits = it.n_splits;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // wide items: 2 x 4 waves, 128 rows x 64 cols each (4 x 2 MFMA tiles per wave);
   // narrow items (wy <= 64): 8 x 1 waves, 32 rows x 64 cols each, so all 8 waves (all 4 SIMDs) work
-  const bool narrow = it.wy <= 64;
+  constexpr bool narrow = NARROW;
   const int wi = narrow ? wave : (wave >> 2), wj = narrow ? 0 : (wave & 3);
   const int i_base = narrow ? 32 * wi : 128 * wi, j_base = 64 * wj;
-  const int na = narrow ? 1 : 4;
+  constexpr int na = narrow ? 1 : 4;
 
   // point range of this split, in stages of WG_NP points
   const int n_stages_total = P_pad / WG_NP;
@@ -77,9 +78,9 @@ msdf_wgrad_k(const msdf_wgrad_item_t* __restrict__ items, const int* __restrict_
   const float* V = (it.v_off >= 0) ? ws + it.v_off : nullptr;
   const bool do_mm = it.wy > 0;
 
-  v16f acc[4][2];
+  v16f acc[na][2];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < na; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -87,9 +88,9 @@ msdf_wgrad_k(const msdf_wgrad_item_t* __restrict__ items, const int* __restrict_
   float colsum = 0.f, vrow = 0.f;
 
   // which of this wave's tiles are inside [wx x wy]
-  bool ai[4], bj[2];
+  bool ai[na], bj[2];
 #pragma unroll
-  for (int a = 0; a < 4; ++a) ai[a] = (a < na) && (i_base + 32 * a) < it.wx;
+  for (int a = 0; a < na; ++a) ai[a] = (i_base + 32 * a) < it.wx;
 #pragma unroll
   for (int b = 0; b < 2; ++b) bj[b] = (j_base + 32 * b) < it.wy;
   const bool wave_active = do_mm && ai[0] && bj[0];
@@ -108,13 +109,13 @@ msdf_wgrad_k(const msdf_wgrad_item_t* __restrict__ items, const int* __restrict_
                                      (__attribute__((address_space(3))) void*)vdst, 4, 0, 0);
   };
 
-  // prologue: up to 3 stages in flight
+  // prologue: WG_NBUF - 1 stages in flight
 #pragma unroll
   for (int j = 0; j < WG_NBUF - 1; ++j)
     if (j < n_st) issue(j);
 
   for (int j = 0; j < n_st; ++j) {
-    // stage j has landed once at most min(2, n_st-1-j) later stages are outstanding
+    // stage j has landed once at most min(WG_NBUF - 2, n_st-1-j) later stages are outstanding
     wg_wait_outstanding(min(WG_NBUF - 2, n_st - 1 - j));
     __builtin_amdgcn_s_barrier();              // every wave's pieces of stage j are in LDS; stage j-1 is fully consumed
     if (j + WG_NBUF - 1 < n_st) issue(j + WG_NBUF - 1);   // refill the buffer stage j-1 used
@@ -125,9 +126,9 @@ msdf_wgrad_k(const msdf_wgrad_item_t* __restrict__ items, const int* __restrict_
       const float* xa = xt + (lane >> 5) * it.wx + i_base + (lane & 31);
       const float* yb = yt + (lane >> 5) * it.wy + j_base + (lane & 31);
       // software-pipelined: the fragments of k-step k+1 are in flight while the 8 MFMAs of step k issue
-      float af[2][4], bf[2][2];
+      float af[2][na], bf[2][2];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) af[0][a] = xa[32 * a];
+      for (int a = 0; a < na; ++a) af[0][a] = xa[32 * a];
 #pragma unroll
       for (int b = 0; b < 2; ++b) bf[0][b] = yb[32 * b];
 #pragma unroll
@@ -135,22 +136,16 @@ msdf_wgrad_k(const msdf_wgrad_item_t* __restrict__ items, const int* __restrict_
         const int cur = k & 1, nxt = cur ^ 1;
         if (k + 1 < WG_NP / 2) {
 #pragma unroll
-          for (int a = 0; a < 4; ++a) af[nxt][a] = xa[2 * (k + 1) * it.wx + 32 * a];
+          for (int a = 0; a < na; ++a) af[nxt][a] = xa[2 * (k + 1) * it.wx + 32 * a];
 #pragma unroll
           for (int b = 0; b < 2; ++b) bf[nxt][b] = yb[2 * (k + 1) * it.wy + 32 * b];
         }
         __builtin_amdgcn_sched_barrier(0);   // keep the prefetch above the MFMAs (the scheduler would sink it)
-        if (narrow) {
+#pragma unroll
+        for (int a = 0; a < na; ++a)
 #pragma unroll
           for (int b = 0; b < 2; ++b)
-            acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][0], bf[cur][b], acc[0][b], 0, 0, 0);
-        } else {
-#pragma unroll
-          for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][a], bf[cur][b], acc[a][b], 0, 0, 0);
-        }
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][a], bf[cur][b], acc[a][b], 0, 0, 0);
       }
     }
     if (it.colsum_off >= 0 && tid < it.wx) {
@@ -167,7 +162,7 @@ msdf_wgrad_k(const msdf_wgrad_item_t* __restrict__ items, const int* __restrict_
   if (wave_active) {
     float* out = part + it.part_off + (size_t)split * it.wx * it.wy;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
+    for (int a = 0; a < na; ++a) {
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         if (ai[a] && bj[b]) {
@@ -185,6 +180,18 @@ msdf_wgrad_k(const msdf_wgrad_item_t* __restrict__ items, const int* __restrict_
   if (it.vrow_off >= 0 && tid >= 256 && (tid - 256) < it.wy)
     part[it.vrow_off + (size_t)split * it.wy + (tid - 256)] = vrow;
 }
+
+__global__ void __launch_bounds__(WG_THREADS, 2)
+msdf_wgrad_k(const msdf_wgrad_item_t* __restrict__ items, const int* __restrict__ wg_map,
+             const float* __restrict__ ws, float* __restrict__ part, const int P_pad) {
+  extern __shared__ float lds_f[];
+  const msdf_wgrad_item_t it = items[wg_map[2 * blockIdx.x]];
+  const int split = wg_map[2 * blockIdx.x + 1];
+  // wide items: 2 x 4 waves of 128 x 64; narrow items (wy <= 64): 8 x 1 waves of 32 x 64
+  if (it.wy <= 64) wgrad_body<true>(it, split, ws, part, P_pad, lds_f);
+  else wgrad_body<false>(it, split, ws, part, P_pad, lds_f);
+}
+
 
 // ---------------------------------------------------------------------------
 // bf16x3 variant: the same items on v_mfma_f32_16x16x32_bf16 (x*y ~ x_hi*y_hi + x_hi*y_lo + x_lo*y_hi).
@@ -212,21 +219,21 @@ __device__ __forceinline__ void wb_split8(const float (&v)[8], wv8bf& hi, wv8bf&
   }
 }
 
-__global__ void __launch_bounds__(WG_THREADS, 2)
-msdf_wgrad_b16_k(const msdf_wgrad_item_t* __restrict__ items, const int* __restrict__ wg_map,
-                 const float* __restrict__ ws, float* __restrict__ part, const int P_pad) {
-  extern __shared__ wv8bf lds_img[];
-  const msdf_wgrad_item_t it = items[wg_map[2 * blockIdx.x]];
-  const int split = wg_map[2 * blockIdx.x + 1];
+// NARROW is a template parameter and tiles are never skipped inside the stage loop (slots past wx / wy are
+// zero in the image; only the final store is guarded): straight-line MFMAs instead of a scalar branch per tile.
+template <bool NARROW>
+__device__ __forceinline__ void wgrad_b16_body(const msdf_wgrad_item_t& it, const int split,
+                                               const float* __restrict__ ws, float* __restrict__ part,
+                                               const int P_pad, wv8bf* lds_img) {
   const int n_splits = it.n_splits;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // wide items: 2 x 4 waves of 128 rows x 64 cols (8 x 4 tiles); narrow (wy <= 64): 8 x 1 waves of 32 x 64
-  const bool narrow = it.wy <= 64;
+  constexpr bool narrow = NARROW;
   const int wi = narrow ? wave : (wave >> 2), wj = narrow ? 0 : (wave & 3);
   const int i_base = narrow ? 32 * wi : 128 * wi, j_base = 64 * wj;
-  const int na = narrow ? 2 : 8;
+  constexpr int na = narrow ? 2 : 8;
 
   const int n_stages_total = P_pad / WB_NP;
   const int per = (n_stages_total + n_splits - 1) / n_splits;
@@ -240,9 +247,9 @@ msdf_wgrad_b16_k(const msdf_wgrad_item_t* __restrict__ items, const int* __restr
   const bool do_mm = it.wy > 0;
   const bool want_vrow = it.vrow_off >= 0;
 
-  wv4f acc[8][4];
+  wv4f acc[na][4];
 #pragma unroll
-  for (int a = 0; a < 8; ++a)
+  for (int a = 0; a < na; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = (wv4f){0.f, 0.f, 0.f, 0.f};
   bool bj[4];
@@ -310,25 +317,21 @@ msdf_wgrad_b16_k(const msdf_wgrad_item_t* __restrict__ items, const int* __restr
       }
       wv8bf ah = img[(i_base >> 4) * 128], al = img[(i_base >> 4) * 128 + 64];
 #pragma unroll
-      for (int a = 0; a < 8; ++a) {
-        if (a < na && (i_base + 16 * a) < it.wx) {
-          wv8bf nh = ah, nl = al;
-          if (a + 1 < 8 && a + 1 < na) {
-            nh = img[((i_base >> 4) + a + 1) * 128];
-            nl = img[((i_base >> 4) + a + 1) * 128 + 64];
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int b = 0; b < 4; ++b) {
-            if (bj[b]) {
-              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[b], acc[a][b], 0, 0, 0);
-              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[b], acc[a][b], 0, 0, 0);
-              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[b], acc[a][b], 0, 0, 0);
-            }
-          }
-          ah = nh;
-          al = nl;
+      for (int a = 0; a < na; ++a) {
+        wv8bf nh = ah, nl = al;
+        if (a + 1 < na) {
+          nh = img[((i_base >> 4) + a + 1) * 128];
+          nl = img[((i_base >> 4) + a + 1) * 128 + 64];
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[b], acc[a][b], 0, 0, 0);
+        }
+        ah = nh;
+        al = nl;
       }
     }
   }
@@ -337,10 +340,10 @@ msdf_wgrad_b16_k(const msdf_wgrad_item_t* __restrict__ items, const int* __restr
   if (wave_active) {
     float* out = part + it.part_off + (size_t)split * it.wx * it.wy;
 #pragma unroll
-    for (int a = 0; a < 8; ++a) {
+    for (int a = 0; a < na; ++a) {
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        if (a < na && bj[b]) {
+        if (bj[b]) {
           const int n = j_base + 16 * b + (lane & 15);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -366,6 +369,17 @@ msdf_wgrad_b16_k(const msdf_wgrad_item_t* __restrict__ items, const int* __restr
     }
   }
 }
+
+__global__ void __launch_bounds__(WG_THREADS, 2)
+msdf_wgrad_b16_k(const msdf_wgrad_item_t* __restrict__ items, const int* __restrict__ wg_map,
+                 const float* __restrict__ ws, float* __restrict__ part, const int P_pad) {
+  extern __shared__ wv8bf lds_img[];
+  const msdf_wgrad_item_t it = items[wg_map[2 * blockIdx.x]];
+  const int split = wg_map[2 * blockIdx.x + 1];
+  if (it.wy <= 64) wgrad_b16_body<true>(it, split, ws, part, P_pad, lds_img);
+  else wgrad_b16_body<false>(it, split, ws, part, P_pad, lds_img);
+}
+
 
 // dst[rowmap[i]*ld + colmap[j]] = scale * sum_b PART[b][i][j]   (fixed summation order: b ascending, so the
 // result is bitwise reproducible).  Four consecutive elements per thread (16-byte loads; wx*wy is a multiple

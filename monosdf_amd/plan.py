@@ -338,15 +338,14 @@ class WgradProgram:
         return np.frombuffer(b''.join(out), dtype=np.uint8).copy()
 
 
-def balanced_program(build, mp, P_pad, target_stages=102):
-    """Split every item's point range into workgroups of about `target_stages` 16-point stages.
+def balanced_program(build, mp, P_pad, target_points=1728):
+    """Split every item's point range into workgroups of about `target_points` points (54 stages of 32).
 
-    Measured on MI355X (scripts/bench_wgrad.py, profiles/README.md): many short workgroups (~50 stages,
-    5 rounds over the 256 CUs) beat one long workgroup per CU by 25 % -- long lock-stepped workgroups run
-    their stages ~40 % slower -- and giving the narrow / column-sum-only items the same split count keeps
-    their latency-bound stages off the critical path."""
-    n_stages = max(1, P_pad // 16)          # the kernel streams 16 points per LDS stage
-    S = max(1, (n_stages + target_stages - 1) // target_stages)
+    Measured on MI355X (scripts/bench_wgrad.py, profiles/README.md): many short workgroups (5 rounds over
+    the 256 CUs at P = 104,448: 61 splits x 21 items) beat one long workgroup per CU by 25 %, the optimum is
+    flat (+-3 % from 59 to 85 splits), and giving the narrow / column-sum-only items the same split count
+    keeps their latency-bound stages off the critical path."""
+    S = max(1, (P_pad + target_points - 1) // target_points)
     return build(mp, P_pad, lambda w: S)
 
 
