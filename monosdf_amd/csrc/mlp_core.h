@@ -17,10 +17,6 @@
 #include "common.h"
 #include "../../include/monosdf_plan.h"
 
-#ifndef MSDF_USE_GLDS
-#define MSDF_USE_GLDS 1   // 1: global_load_lds (LDS-DMA) staging, 0: register staging
-#endif
-
 #define MT MSDF_MAX_TILES   // 17
 #define MLP_THREADS 256
 #define MLP_PTS_PER_WAVE 16
@@ -39,8 +35,7 @@ __device__ __forceinline__ v4f mfma4(const v4f a, const v4f b, v4f c) {
   return c;
 }
 
-// Copy one weight chunk (n_f4 float4, a multiple of 64) global -> LDS, linear image.
-#if MSDF_USE_GLDS
+// Copy one weight chunk (n_f4 float4, a multiple of 64) global -> LDS with LDS-DMA, linear image.
 template <int PIECES_MAX>
 __device__ __forceinline__ void chunk_issue(const v4f* __restrict__ src, v4f* dst, const int n_f4) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: keeps the branch below uniform
@@ -55,7 +50,6 @@ __device__ __forceinline__ void chunk_issue(const v4f* __restrict__ src, v4f* ds
     }
   }
 }
-#endif
 
 // acc[0..OT) += W * in, W given as the fragment-ordered pack [ceil2(OT)][K][64] float4.
 // KT_T > 0: K is the compile-time constant KT_T (fully unrolled, no guards);
@@ -178,25 +172,6 @@ __device__ __forceinline__ void gemm_dispatch(const int kp, v4f (&acc)[MT], cons
     case 17: gemm_tiles<17>(acc, in, OT, 17, wsrc, lds, tail); break;
     default: gemm_tiles<0>(acc, in, OT, kp, wsrc, lds, tail); break;
   }
-}
-
-// Pull the 16-point x (16*tiles)-float rows this wave will read after the next GEMM towards L2:
-// one dword per 128-byte line.  The values are kept in a tiny struct that the caller retires with
-// touch_retire() AFTER the GEMM, so the compiler's own s_waitcnt lands there (latency hidden by the GEMM).
-struct Touch { float v[3]; };
-__device__ __forceinline__ Touch touch_rows(const float* __restrict__ row0, const int tiles) {
-  const int bytes = 16 * 16 * 4 * tiles;     // 16 points x 64 B per tile
-  const char* base = (const char*)row0;
-  Touch t;
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int off = (lane_id() + 64 * i) * 128;
-    t.v[i] = (off < bytes) ? *(const float*)(base + off) : 0.f;
-  }
-  return t;
-}
-__device__ __forceinline__ void touch_retire(const Touch& t) {
-  asm volatile("" ::"v"(t.v[0]), "v"(t.v[1]), "v"(t.v[2]));
 }
 
 __device__ __forceinline__ void zero_tiles(v4f (&a)[MT]) {

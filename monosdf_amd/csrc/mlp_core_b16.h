@@ -13,9 +13,6 @@
 // hi plane then lo plane (1 KB each).
 #pragma once
 #include "mlp_core.h"
-#ifndef B16_EXP
-#define B16_EXP 0   // tuning experiments only (scripts/bench_b16.py); 0 = product code
-#endif
 
 
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
@@ -128,11 +125,7 @@ __device__ __forceinline__ void gemm_b16(v4f (&acc)[MT], const B16Act& act, cons
   for (int c = 0; c < (MT + B16_CHUNK_OT - 1) / B16_CHUNK_OT; ++c) {
     if (c < nchunks) {
       const int buf = c & 1;
-#if B16_EXP == 3
-      if (c + 1 < nchunks && c == 0)
-#else
       if (c + 1 < nchunks)
-#endif
         b16_chunk_issue<B16_CHUNK_OT * KMAX * 2>(wsrc + (size_t)(c + 1) * ch_v8, lds + (buf ^ 1) * B16_BUF_V8, ch_v8);
       const v8bf* w = lds + buf * B16_BUF_V8 + lane;      // [ot in chunk][kb][hi|lo][64]
       // LDS base of this chunk as an opaque 32-bit register: every fragment read below then carries its
@@ -173,13 +166,9 @@ __device__ __forceinline__ void gemm_b16(v4f (&acc)[MT], const B16Act& act, cons
                 fl[(i + 2) % 3] = B16_FRAG(i + 2, 1);
               }
               __builtin_amdgcn_sched_barrier(0);
-#if B16_EXP == 2
-              cc[0] += (float)fh[i % 3][0] * (float)act.hi[kb][0] + (float)fl[i % 3][1] * (float)act.lo[kb][0];
-#else
               cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[i % 3], act.hi[kb], cc, 0, 0, 0);
               cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[i % 3], act.lo[kb], cc, 0, 0, 0);
               cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl[i % 3], act.hi[kb], cc, 0, 0, 0);
-#endif
             }
             epi(oi, cc);
             acc[oi] = cc;

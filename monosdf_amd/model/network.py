@@ -47,12 +47,6 @@ class WNLinear(nn.Module):
         return self.weight
 
 
-def _flat_params(layers):
-    w = torch.cat([l.effective_weight().reshape(-1) for l in layers])
-    b = torch.cat([l.bias.reshape(-1) for l in layers])
-    return w, b
-
-
 class _FusedNet(nn.Module):
     """Shared plumbing: lazily created device state + per-call packing of the effective weights."""
 
