@@ -162,12 +162,14 @@ __device__ __forceinline__ void gemm_tiles(v4f (&acc)[MT], const v4f (&in)[MT], 
   }
 }
 
-// Specialised for the K values of the 256-wide networks; anything else takes the guarded path.
+// Specialised for the K values of the 256-wide networks (3 = PE, 5 = PE + hash-grid features, 16, 17 = skip
+// layer); anything else takes the guarded path.
 template <class Tail>
 __device__ __forceinline__ void gemm_dispatch(const int kp, v4f (&acc)[MT], const v4f (&in)[MT], const int OT,
                                               const v4f* __restrict__ wsrc, v4f* lds, const Tail& tail) {
   switch (kp) {
     case 3: gemm_tiles<3>(acc, in, OT, 3, wsrc, lds, tail); break;
+    case 5: gemm_tiles<5>(acc, in, OT, 5, wsrc, lds, tail); break;      // PE + hash-grid features
     case 16: gemm_tiles<16>(acc, in, OT, 16, wsrc, lds, tail); break;
     case 17: gemm_tiles<17>(acc, in, OT, 17, wsrc, lds, tail); break;
     default: gemm_tiles<0>(acc, in, OT, kp, wsrc, lds, tail); break;

@@ -185,6 +185,8 @@ template <class Epi>
 __device__ __forceinline__ void gemm_b16_dispatch(const int kbp, v4f (&acc)[MT], const B16Act& act, const int OT,
                                                   const v8bf* __restrict__ wsrc, v8bf* lds, const Epi& epi) {
   switch (kbp) {
+    case 2: gemm_b16<2>(acc, act, OT, 2, wsrc, lds, epi); break;     // PE (3 tiles)
+    case 3: gemm_b16<3>(acc, act, OT, 3, wsrc, lds, epi); break;     // PE + hash-grid features (5 tiles)
     case 8: gemm_b16<8>(acc, act, OT, 8, wsrc, lds, epi); break;
     case 9: gemm_b16<9>(acc, act, OT, 9, wsrc, lds, epi); break;
     default: gemm_b16<0>(acc, act, OT, kbp, wsrc, lds, epi); break;

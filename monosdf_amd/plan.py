@@ -95,7 +95,9 @@ class MlpPlan:
         off = 0
         for u in range(self.plan.n_layers):
             L = p16.layer[u]
-            L.ktp, L.otp = (L.kt + 1) // 2, (L.ot + 1) // 2
+            # K blocks of 32 slots; 6..8 blocks share the unrolled 8-block path (zero weights in the padding)
+            kb = lambda t: 8 if 6 <= (t + 1) // 2 <= 8 else (t + 1) // 2
+            L.ktp, L.otp = kb(L.kt), kb(L.ot)
             L.wf_off = off
             off += (L.ot + 3) // 4 * 4 * L.ktp * 2 * 64      # out tiles padded to the 4-tile LDS chunk
             L.wb_off = off
