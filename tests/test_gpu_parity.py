@@ -340,3 +340,33 @@ def test_fused_probe_loss_matches_torch_autograd():
     (2.0 * l).backward()
     for (k, t), gr in zip(gpu_in.items(), g_ref):
         assert rel_err(t.grad, 2.0 * gr) < 1e-5, k
+
+
+@pytest.mark.parametrize('n_rays', [1, 5, 67])
+def test_ragged_batches_against_oracle(n_rays, precision):
+    """Batches that fill neither a wave (16 points) nor a workgroup (64): 1, 5 and 67 rays, training mode,
+    forward + backward against the oracle on the same rays and the same random draws."""
+    from oracle import config, monosdf_oracle as mo, synth
+    from monosdf_amd.conf import ConfigTree
+    from monosdf_amd.model.network import MonoSDFNetwork
+    conf = config.mlp_config(width=64, depth=8)
+    state = synth.make_state(conf, seed=3, jitter=0.3)
+    rays = synth.make_rays(n_rays, seed=4, random_pose=True)
+    noise = synth.make_noise(conf, n_rays, 128, seed=5)
+    model = MonoSDFNetwork(ConfigTree.from_dict(conf))
+    model.load_state_dict(state, strict=True)
+    model = model.cuda().train().set_precision(precision)
+    model._noise = _cuda(noise)
+    idx = torch.arange(n_rays)
+    out = model(_cuda(rays), idx.cuda(), if_pixel_input=True)
+    mo.probe_loss(out).backward()
+    st = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in state.items()}
+    ref = mo.render(st, conf, rays, idx, True, True, noise)
+    mo.probe_loss(ref).backward()
+    for k in ('rgb_values', 'depth_values', 'normal_map', 'grad_theta', 'weights', 'sdf'):
+        assert out[k].shape == ref[k].shape, k
+        assert rel_err(out[k], ref[k]) < 5e-4, (k, rel_err(out[k], ref[k]))
+    params = dict(model.named_parameters())
+    for n in ('implicit_network.lin4.weight_v', 'implicit_network.lin0.bias', 'rendering_network.lin1.weight_g',
+              'density.beta'):
+        assert rel_err(params[n].grad, st[n].grad) < 2e-3, (n, rel_err(params[n].grad, st[n].grad))
