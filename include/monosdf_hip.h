@@ -22,6 +22,17 @@
  *       composites (model/network.py:552-562, 603-605, 626-640) and their backward.
  *   msdf_sampler_* (see below)
  *       ErrorBoundSampler.get_z_vals / UniformSampler.get_z_vals (model/ray_sampler.py:48-83, 110-272).
+ *   msdf_weightnorm_forward, msdf_weightnorm_backward
+ *       the nn.utils.weight_norm hooks of every Linear (model/network.py:72-73, 239-240, 381-382).
+ *   msdf_camera_rays
+ *       rend_util.get_camera_params + lift, called twice per chunk (utils/rend_util.py:63-91, 105-118;
+ *       model/network.py:505-516).
+ *   msdf_monosdf_loss
+ *       MonoSDFLoss.forward and its backward (model/loss.py:180-311 with 29-87, 156-171).
+ *   msdf_probe_loss
+ *       no reference counterpart: the fixed scalar bench.py differentiates.
+ *
+ * Entry points that take an msdf_plan_t run on the matrix core named by plan->precision (monosdf_plan.h).
  */
 #ifndef MONOSDF_HIP_H
 #define MONOSDF_HIP_H
