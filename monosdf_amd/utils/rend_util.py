@@ -1,30 +1,17 @@
-"""Ray generation for image-mode inputs (reference: code/utils/rend_util.py:63-91, 105-118).
-The step immediately before the hot path; a handful of [N]-sized tensor ops."""
+"""Image-side helpers of the reference's utils/rend_util.py that the render drivers use.
+Ray generation (get_camera_params + lift, rend_util.py:63-91,105-118) is the HIP kernel `msdf_camera_rays`
+(csrc/rays.hip, ops.camera_rays)."""
 import torch
-from torch.nn import functional as F
-
-
-def lift(x, y, z, intrinsics):
-    fx, fy = intrinsics[:, 0, 0].unsqueeze(-1), intrinsics[:, 1, 1].unsqueeze(-1)
-    cx, cy = intrinsics[:, 0, 2].unsqueeze(-1), intrinsics[:, 1, 2].unsqueeze(-1)
-    sk = intrinsics[:, 0, 1].unsqueeze(-1)
-    x_lift = (x - cx + cy * sk / fy - sk * y / fy) / fx * z
-    y_lift = (y - cy) / fy * z
-    return torch.stack((x_lift, y_lift, z, torch.ones_like(z)), dim=-1)
 
 
 def get_camera_params(uv, pose, intrinsics):
-    if pose.shape[1] == 7:
-        raise NotImplementedError('quaternion poses are not used on this path')
-    cam_loc = pose[:, :3, 3]
-    batch_size, num_samples, _ = uv.shape
-    x_cam = uv[:, :, 0].view(batch_size, -1)
-    y_cam = uv[:, :, 1].view(batch_size, -1)
-    z_cam = torch.ones_like(x_cam)
-    pts = lift(x_cam, y_cam, z_cam, intrinsics).permute(0, 2, 1)
-    world = torch.bmm(pose, pts).permute(0, 2, 1)[:, :, :3]
-    ray_dirs = F.normalize(world - cam_loc[:, None, :], dim=2)
-    return ray_dirs, cam_loc
+    """Reference signature (rend_util.py:63): uv [1,n,2], pose [1,4,4], intrinsics [1,4,4] ->
+    (ray_dirs [1,n,3], cam_loc [1,3])."""
+    from .. import ops
+    if pose.shape[0] != 1 or pose.shape[1:] != (4, 4):
+        raise NotImplementedError('one 4x4 camera-to-world pose per call (quaternion poses are not used on this path)')
+    dirs, _, cam = ops.camera_rays(uv[0], pose[0], intrinsics[0])
+    return dirs.unsqueeze(0), cam[:1]
 
 
 def get_psnr(img1, img2, normalize_rgb=False):
