@@ -370,3 +370,46 @@ def test_ragged_batches_against_oracle(n_rays, precision):
     for n in ('implicit_network.lin4.weight_v', 'implicit_network.lin0.bias', 'rendering_network.lin1.weight_g',
               'density.beta'):
         assert rel_err(params[n].grad, st[n].grad) < 2e-3, (n, rel_err(params[n].grad, st[n].grad))
+
+
+def test_ddp_wrapped_training_step_matches_plain():
+    """The reference wraps the model in DistributedDataParallel(device_ids=[rank], broadcast_buffers=False,
+    find_unused_parameters=True) (monosdf_train.py:228-229): one RCCL-backed step (world size 1) must give the
+    gradients of the unwrapped model -- the custom autograd nodes and the side stream sit below DDP's hooks."""
+    import os
+    import torch.distributed as dist
+    from monosdf_amd.model.loss import MonoSDFLoss
+    c = Case('mlp_w64_train')
+    plain = _model(c, training=True)
+    wrapped_inner = _model(c, training=True)
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        ddp = torch.nn.parallel.DistributedDataParallel(wrapped_inner, device_ids=[0], broadcast_buffers=False,
+                                                        find_unused_parameters=True)
+        gt = None
+        losses = []
+        for m in (plain, ddp):
+            inner = m.module if hasattr(m, 'module') else m
+            inner._noise = _cuda(c.noise)
+            out = m(_cuda(c.inputs), c.indices.cuda(), if_pixel_input=c.pixel)
+            N = out['rgb_values'].shape[0]
+            if gt is None:
+                g = torch.Generator().manual_seed(1)
+                gt = {'rgb': torch.rand(1, N, 3, generator=g), 'depth': torch.rand(1, N, 1, generator=g) * 0.04,
+                      'normal': torch.randn(1, N, 3, generator=g), 'mask': torch.ones(1, N, 1)}
+            loss = MonoSDFLoss(rgb_loss='torch.nn.L1Loss', eikonal_weight=0.05)(out, gt, if_pixel_input=True)['loss']
+            loss.backward()
+            losses.append(loss.item())
+        assert losses[0] == losses[1]
+        gp = dict(plain.named_parameters())
+        for name, p in wrapped_inner.named_parameters():
+            assert (p.grad is None) == (gp[name].grad is None), name
+            if p.grad is not None:
+                assert torch.equal(p.grad, gp[name].grad), name
+    finally:
+        if created:
+            dist.destroy_process_group()
