@@ -85,6 +85,36 @@ class ErrorBoundSampler(RaySampler):
         a.M = n_eval
         _lib.call('msdf_sampler_init', C.byref(a), st)
         rounds, M = 0, n_eval
+        z_out = z_eik = x_all = extra_idx = eik_idx = None
+
+        def prepare_finish():
+            """Everything the finish kernel needs that does not depend on the number of rounds -- issued while the
+            GPU is still busy with the first round, so that after the host sync below only the launch is left."""
+            nonlocal z_out, z_eik, x_all, extra_idx, eik_idx
+            eik_idx = noise.get('eik_idx')
+            if eik_idx is None:
+                eik_idx = torch.randint(S, (N,), device=dev)
+            eik_idx = eik_idx.to(device=dev, dtype=torch.int64).contiguous()
+            z_out = torch.empty(N, S, **f32)
+            z_eik = torch.empty(N, 1, **f32)
+            a.eik_idx, a.z_out, a.z_eik, a.pts_out = eik_idx.data_ptr(), z_out.data_ptr(), z_eik.data_ptr(), None
+            if want_points:
+                n_eik = 4 * N if training else 0
+                x_all = torch.empty(N * S + n_eik, 3, **f32)
+                a.pts_out = x_all.data_ptr()
+                if training:
+                    R = self.scene_bounding_sphere
+                    eik_uniform = noise.get('eik_uniform')
+                    eik_uniform = (torch.empty(N, 3, **f32).uniform_(-R, R) if eik_uniform is None
+                                   else eik_uniform.to(**f32).contiguous())
+                    nei = noise.get('nei_rand')
+                    nei = torch.rand(2 * N, 3, **f32) if nei is None else nei.to(**f32).contiguous()
+                    a.eik_uniform, a.nei_rand = eik_uniform.data_ptr(), nei.data_ptr()
+                    self._keep = (eik_uniform, nei)
+            # the 32 extra columns for the one-round case (the common one); redrawn below if more rounds ran
+            if n_extra > 0 and training and noise.get('extra_idx') is None:
+                extra_idx = torch.randperm(n_eval, device=dev)[:n_extra].contiguous()
+
         with torch.no_grad():
             while True:
                 new_sdf = net.get_sdf_vals(pts)                       # fused forward kernel, [N*n_eval, 1]
@@ -93,6 +123,8 @@ class ErrorBoundSampler(RaySampler):
                 a.flag = flags.data_ptr() + 8 * rounds
                 _lib.call('msdf_sampler_beta', C.byref(a), st)
                 _lib.call('msdf_sampler_resample', C.byref(a), st)
+                if rounds == 0:
+                    prepare_finish()
                 more = int(flags[2 * rounds + 1].item())              # the one host sync of the round
                 rounds += 1
                 if not more:
@@ -101,35 +133,16 @@ class ErrorBoundSampler(RaySampler):
         self.last_rounds = rounds
         # final set: 64 importance samples + near + far + 32 columns of the dense set
         if n_extra > 0:
-            extra_idx = noise.get('extra_idx') if training else None
-            if extra_idx is None:
-                # drawn on the device (the reference draws on the CPU generator; same distribution, no H2D copy)
-                extra_idx = (torch.randperm(M, device=dev)[:n_extra] if training
-                             else torch.linspace(0, M - 1, n_extra, device=dev).long())
+            if not training or noise.get('extra_idx') is not None or M != n_eval:
+                extra_idx = noise.get('extra_idx') if training else None
+                if extra_idx is None:
+                    # drawn on the device (the reference draws on the CPU generator; same distribution, no H2D copy)
+                    extra_idx = (torch.randperm(M, device=dev)[:n_extra] if training
+                                 else torch.linspace(0, M - 1, n_extra, device=dev).long())
             extra_idx = extra_idx.to(device=dev, dtype=torch.int64).contiguous()
         else:
             extra_idx = torch.zeros(1, device=dev, dtype=torch.int64)
-        eik_idx = noise.get('eik_idx')
-        if eik_idx is None:
-            eik_idx = torch.randint(S, (N,), device=dev)
-        eik_idx = eik_idx.to(device=dev, dtype=torch.int64).contiguous()
-        z_out = torch.empty(N, S, **f32)
-        z_eik = torch.empty(N, 1, **f32)
         a.M = M
-        a.extra_idx, a.eik_idx = extra_idx.data_ptr(), eik_idx.data_ptr()
-        a.z_out, a.z_eik, a.pts_out = z_out.data_ptr(), z_eik.data_ptr(), None
-        x_all = None
-        if want_points:
-            n_eik = 4 * N if training else 0
-            x_all = torch.empty(N * S + n_eik, 3, **f32)
-            a.pts_out = x_all.data_ptr()
-            if training:
-                R = self.scene_bounding_sphere
-                eik_uniform = noise.get('eik_uniform')
-                eik_uniform = (torch.empty(N, 3, **f32).uniform_(-R, R) if eik_uniform is None
-                               else eik_uniform.to(**f32).contiguous())
-                nei = noise.get('nei_rand')
-                nei = torch.rand(2 * N, 3, **f32) if nei is None else nei.to(**f32).contiguous()
-                a.eik_uniform, a.nei_rand = eik_uniform.data_ptr(), nei.data_ptr()
+        a.extra_idx = extra_idx.data_ptr()
         _lib.call('msdf_sampler_finish', C.byref(a), st)
         return z_out, z_eik, x_all
