@@ -335,6 +335,7 @@ class MonoSDFNetwork(nn.Module):
         self.density = LaplaceDensity(**conf.get_config('density'))
         self.ray_sampler = ErrorBoundSampler(self.scene_bounding_sphere, **conf.get_config('ray_sampler'))
         self._noise = None      # tests inject the six random draws here (SURVEY.md 8(a) RNG note)
+        self.speculate_rounds = os.environ.get('MSDF_SPECULATE_ROUNDS', '1') != '0'   # see forward()
 
     def set_precision(self, precision):
         """'fp32' or 'bf16x3' matrix core for the fused MLP kernels (not a reference option)."""
@@ -376,22 +377,30 @@ class MonoSDFNetwork(nn.Module):
         net.share(device)
         self.rendering_network.share(device)
         try:
-            # the sampler's last kernel also writes the sample points and (training) the eikonal points
-            z_vals, z_samples_eik, x_all = self.ray_sampler.sample(ray_dirs, cam_loc, self)
-            N, S = z_vals.shape
-            P = N * S
-            points_flat = x_all[:P]
-            # one fused evaluation for the ray samples (clamped, with features) and the eikonal points
-            sdf_all, feature_vectors, grad_all = net.evaluate(x_all, P, P, save=torch.is_grad_enabled())
-            sdf, gradients_sdf = sdf_all[:P], grad_all[:P]
-            rgb_flat = self.rendering_network(points_flat, gradients_sdf, ray_dirs, feature_vectors, indices,
-                                              if_pixel_input=if_pixel_input, samples_per_ray=S)['rgb']
-            rgb = rgb_flat.reshape(-1, S, 3)
-            # the compositor also rotates the normal map into the camera frame (R^T, reference 608-616)
             pose = input_dict['ray_pose'] if if_pixel_input else input_dict['pose'][:1]
-            weights, rgb_values, depth_values, normal_map = ops.CompositeFunction.apply(
-                z_vals, sdf, rgb_flat, gradients_sdf, self.density.get_beta(), depth_scale, self.white_bkgd,
-                self._bg_list(), pose)
+            # The sampler reads one batch-global flag per round back to the host, and the GPU would drain while the
+            # host waits and then issues the big kernels.  So the first attempt runs as many rounds as the previous
+            # call needed WITHOUT reading the flags, enqueues everything, and only then looks at them (they have
+            # been on their way since the sampler kernels finished); a wrong guess repeats the pass with the syncs.
+            guess = max(1, self.ray_sampler.last_rounds) if self.speculate_rounds else 0
+            for attempt in (guess, 0):
+                # the sampler's last kernel also writes the sample points and (training) the eikonal points
+                z_vals, z_samples_eik, x_all = self.ray_sampler.sample(ray_dirs, cam_loc, self, speculate=attempt)
+                N, S = z_vals.shape
+                P = N * S
+                points_flat = x_all[:P]
+                # one fused evaluation for the ray samples (clamped, with features) and the eikonal points
+                sdf_all, feature_vectors, grad_all = net.evaluate(x_all, P, P, save=torch.is_grad_enabled())
+                sdf, gradients_sdf = sdf_all[:P], grad_all[:P]
+                rgb_flat = self.rendering_network(points_flat, gradients_sdf, ray_dirs, feature_vectors, indices,
+                                                  if_pixel_input=if_pixel_input, samples_per_ray=S)['rgb']
+                rgb = rgb_flat.reshape(-1, S, 3)
+                # the compositor also rotates the normal map into the camera frame (R^T, reference 608-616)
+                weights, rgb_values, depth_values, normal_map = ops.CompositeFunction.apply(
+                    z_vals, sdf, rgb_flat, gradients_sdf, self.density.get_beta(), depth_scale, self.white_bkgd,
+                    self._bg_list(), pose)
+                if attempt == 0 or self.ray_sampler.confirm():
+                    break
         finally:
             net.unshare()
             self.rendering_network.unshare()

@@ -31,6 +31,7 @@ class ErrorBoundSampler(RaySampler):
         self.scene_bounding_sphere = scene_bounding_sphere
         self.add_tiny = add_tiny
         self.last_rounds = 0
+        self._pending = None
         # Lemma-2 constant, formed in fp32 like the reference does (ray_sampler.py:119)
         self._lemma = float(1.0 / (4.0 * torch.log(torch.tensor(self.eps + 1.0))))
 
@@ -38,9 +39,23 @@ class ErrorBoundSampler(RaySampler):
         z, z_eik, _ = self.sample(ray_dirs, cam_loc, model, want_points=False)
         return z, z_eik
 
-    def sample(self, ray_dirs, cam_loc, model, want_points=True):
+    def confirm(self):
+        """After a speculative sample(): True if the convergence flags ask for exactly the rounds that were run."""
+        if self._pending is None:
+            return True
+        ev, host, k = self._pending
+        self._pending = None
+        ev.synchronize()
+        more = [int(host[2 * r + 1]) for r in range(k)]
+        return all(more[:k - 1]) and not more[k - 1]
+
+    def sample(self, ray_dirs, cam_loc, model, want_points=True, speculate=0):
         """get_z_vals plus (optionally) the 3-D points of the ray samples and, in training, the eikonal
-        points appended behind them -- written by the finish kernel instead of ~15 small tensor ops."""
+        points appended behind them -- written by the finish kernel instead of ~15 small tensor ops.
+
+        speculate = k > 0: run exactly k rounds WITHOUT reading the batch-global convergence flag back (the one
+        host sync per round, during which the GPU would drain); the caller enqueues the rest of its work and
+        then calls confirm(), which tells whether k was the number of rounds the flags ask for."""
         dev = ray_dirs.device
         if not ray_dirs.is_cuda:
             raise RuntimeError('monosdf_amd: the sampler runs on the GPU only (no CPU fallback)')
@@ -125,11 +140,21 @@ class ErrorBoundSampler(RaySampler):
                 _lib.call('msdf_sampler_resample', C.byref(a), st)
                 if rounds == 0:
                     prepare_finish()
-                more = int(flags[2 * rounds + 1].item())              # the one host sync of the round
+                if speculate > 0:
+                    more = int(rounds + 1 < speculate)
+                else:
+                    more = int(flags[2 * rounds + 1].item())          # the one host sync of the round
                 rounds += 1
                 if not more:
                     break
                 M += n_eval
+        self._pending = None
+        if speculate > 0:
+            host = torch.empty(flags.shape, dtype=flags.dtype, pin_memory=True)
+            host.copy_(flags, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._pending = (ev, host, rounds)
         self.last_rounds = rounds
         # final set: 64 importance samples + near + far + 32 columns of the dense set
         if n_extra > 0:
