@@ -27,6 +27,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_RAYS = 1024
+# entry points timed with HIP events inside the timed region (the kernels that make up >95 % of a step)
+TIMED = {'msdf_sdf_forward', 'msdf_sdf_fwd_grad', 'msdf_sdf_backward', 'msdf_wgrad', 'msdf_reduce',
+         'msdf_color_forward', 'msdf_color_backward', 'msdf_hash_encode_forward', 'msdf_hash_encode_backward',
+         'msdf_hash_encode_second_backward'}
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 
 
@@ -181,6 +185,7 @@ def main():
             step()
         rounds = model.ray_sampler.last_rounds
         _lib.PROFILE = {}
+        _lib.PROFILE_NAMES = TIMED
         barrier()
         t0 = time.time()
         for _ in range(args.steps):
