@@ -230,9 +230,9 @@ def main():
               'unit': 'TFLOP/s', 'frac': flops[dom] / t / 1e12 / F32_MFMA_PEAK_TFLOPS, 'traffic': None,
               'avg_kernel_ms': kern[dom]['avg_ms']}
         # rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE per launch of the same command,
-        # profiles/r01_v7_pmc_{fp32,bf16x3}.json (separate passes; the kernels' data movement is fixed by P)
-        measured = {'fp32': {'msdf_sdf_backward': 6.660e9, 'msdf_sdf_fwd_grad': 2.936e9, 'msdf_sdf_forward': 2.3e7},
-                    'bf16x3': {'msdf_sdf_backward': 6.552e9, 'msdf_sdf_fwd_grad': 3.065e9, 'msdf_sdf_forward': 1.05e8}}
+        # profiles/r01_v8_pmc_{fp32,bf16x3}.json (separate passes; the kernels' data movement is fixed by P)
+        measured = {'fp32': {'msdf_sdf_backward': 6.650e9, 'msdf_sdf_fwd_grad': 2.937e9, 'msdf_sdf_forward': 2.3e7},
+                    'bf16x3': {'msdf_sdf_backward': 6.503e9, 'msdf_sdf_fwd_grad': 3.061e9, 'msdf_sdf_forward': 1.05e8}}
         mf['traffic'] = measured[m['precision']].get(dom)
         hb = None
         if dom in hbm:
