@@ -49,7 +49,7 @@ extern "C" {
 #define MSDF_ERR_LAUNCH 2
 #define MSDF_ERR_UNSUPPORTED 3
 
-#define MSDF_ABI_VERSION 2
+#define MSDF_ABI_VERSION 3
 int msdf_abi_version(void);
 
 /* ---- hash grid (reference: hashencoder/src/hashencoder.h:13-15) ---- */
@@ -123,10 +123,12 @@ typedef struct {
   const float* x;
   int32_t P, P_pad;
   int32_t n_feat;
-  int32_t pad_;
-  const float* g_sdf;      /* [P] or NULL */
+  int32_t n_split;         /* points [0, n_split) take g_sdf / g_nrm, points [n_split, P) take g_sdf_b / g_nrm_b:
+                              the two groups (ray samples | eikonal points) get their gradients from different
+                              consumers, and this spares the caller the zero-fill + copy + add of joining them */
+  const float* g_sdf;      /* [n_split] or NULL */
   const float* g_feat;     /* [n_feat, 16*feat_tiles] or NULL */
-  const float* g_nrm;      /* [P,3] or NULL */
+  const float* g_nrm;      /* [n_split,3] or NULL */
   const float* g_raux;     /* [P, 16*aux_tiles] or NULL */
   const unsigned char* clamped;
   const float* H;
@@ -137,6 +139,8 @@ typedef struct {
   float* GSDF;             /* [P_pad] */
   float* QLAST;            /* [P_pad, 16*kt_last] */
   float* g_aux;            /* [P, 16*aux_tiles] or NULL */
+  const float* g_sdf_b;    /* [P - n_split] or NULL */
+  const float* g_nrm_b;    /* [P - n_split, 3] or NULL */
 } msdf_bw_args_t;
 int msdf_sdf_backward(const msdf_plan_t* plan, const msdf_bw_args_t* args, void* stream);
 

@@ -59,10 +59,10 @@ class FgArgs(C.Structure):
 
 class BwArgs(C.Structure):
     _fields_ = [('wpack', _P), ('bpack', _P), ('x', _P),
-                ('P', C.c_int32), ('P_pad', C.c_int32), ('n_feat', C.c_int32), ('pad_', C.c_int32),
+                ('P', C.c_int32), ('P_pad', C.c_int32), ('n_feat', C.c_int32), ('n_split', C.c_int32),
                 ('g_sdf', _P), ('g_feat', _P), ('g_nrm', _P), ('g_raux', _P), ('clamped', _P),
                 ('H', _P), ('PM', _P), ('QB', _P), ('T', _P), ('AB', _P), ('GSDF', _P), ('QLAST', _P),
-                ('g_aux', _P)]
+                ('g_aux', _P), ('g_sdf_b', _P), ('g_nrm_b', _P)]
 
 
 class ColorFwdArgs(C.Structure):
@@ -175,7 +175,7 @@ def load():
         fn = getattr(lib, name)        # AttributeError if the symbol is missing: intended
         fn.argtypes = argtypes
         fn.restype = C.c_int
-    if lib.msdf_abi_version() != 2:
+    if lib.msdf_abi_version() != 3:
         raise RuntimeError('monosdf_amd: ABI version mismatch, rebuild the library')
     _lib = lib
     return lib

@@ -273,11 +273,16 @@ __device__ __forceinline__ void sdf_backward_body(const msdf_plan_t& plan, const
   const bool live = c.valid && !(a.clamped != nullptr && a.clamped[c.ptc]);
   float gs = 0.f, gn0 = 0.f, gn1 = 0.f, gn2 = 0.f;
   if (live) {
-    if (a.g_sdf) gs = a.g_sdf[c.pt];
-    if (a.g_nrm) {
-      gn0 = a.g_nrm[(size_t)c.pt * 3 + 0];
-      gn1 = a.g_nrm[(size_t)c.pt * 3 + 1];
-      gn2 = a.g_nrm[(size_t)c.pt * 3 + 2];
+    // two groups of points with separately produced gradients (ray samples | eikonal points)
+    const bool first = c.pt < a.n_split;
+    const float* gsp = first ? a.g_sdf : a.g_sdf_b;
+    const float* gnp = first ? a.g_nrm : a.g_nrm_b;
+    const size_t j = first ? (size_t)c.pt : (size_t)(c.pt - a.n_split);
+    if (gsp) gs = gsp[j];
+    if (gnp) {
+      gn0 = gnp[j * 3 + 0];
+      gn1 = gnp[j * 3 + 1];
+      gn2 = gnp[j * 3 + 2];
     }
   }
   if (c.q == 0) a.GSDF[c.pt] = gs;

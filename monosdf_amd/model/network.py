@@ -144,9 +144,10 @@ class _SdfBase(_FusedNet):
                                       self.feature_vector_size)
 
     # -- one fused evaluation -------------------------------------------------------------
-    def evaluate(self, x, n_clamp, n_feat, save=None):
+    def evaluate(self, x, n_clamp, n_feat, save=None, split=None):
         """sdf [P,1], feat [n_feat,F], d sdf/dx [P,3] for the points x; the first n_clamp points get the
-        bounding-sphere clamp, the first n_feat points get feature vectors."""
+        bounding-sphere clamp, the first n_feat points get feature vectors.
+        split = s: returns (sdf [:s], feat, d sdf/dx [:s], d sdf/dx [s:]) as separate tensors."""
         if save is None:
             save = torch.is_grad_enabled()
         x = x.detach()
@@ -156,13 +157,19 @@ class _SdfBase(_FusedNet):
             aux, handle = self.encoding.encode_with_jacobian((x / self.divide_factor + 1.0) / 2.0)
             aux = self._pad_aux(aux)
         radius = self.sdf_bounding_sphere if self.clamps else 0.0
-        sdf, feat, nrm, r_aux = ops.SdfMlpFunction.apply(x, aux, flat_w, flat_b, wpack, bpack, fused, int(n_clamp),
-                                                         int(n_feat), radius, self.sphere_scale, bool(save))
+        ns = x.shape[0] if split is None else int(split)
+        sdf, _, feat, nrm, nrm_b, r_aux = ops.SdfMlpFunction.apply(
+            x, aux, flat_w, flat_b, wpack, bpack, fused, int(n_clamp), int(n_feat), radius, self.sphere_scale,
+            bool(save), ns)
         if self.aux_active:
             # chain rule through x01 = (x / divide_factor + 1) / 2
             r_aux = r_aux[:, :self.aux_cols]
-            nrm = nrm + self.encoding.input_gradient(handle, r_aux) * (0.5 / self.divide_factor)
-        return sdf, feat, nrm
+            through_grid = self.encoding.input_gradient(handle, r_aux) * (0.5 / self.divide_factor)
+            nrm = nrm + through_grid[:ns]
+            nrm_b = nrm_b + through_grid[ns:]
+        if split is None:
+            return sdf, feat, nrm
+        return sdf, feat, nrm, nrm_b
 
     def _pad_aux(self, aux):
         """The kernels read whole 16-slot tiles of grid features."""
@@ -390,8 +397,8 @@ class MonoSDFNetwork(nn.Module):
                 P = N * S
                 points_flat = x_all[:P]
                 # one fused evaluation for the ray samples (clamped, with features) and the eikonal points
-                sdf_all, feature_vectors, grad_all = net.evaluate(x_all, P, P, save=torch.is_grad_enabled())
-                sdf, gradients_sdf = sdf_all[:P], grad_all[:P]
+                sdf, feature_vectors, gradients_sdf, grad_eik = net.evaluate(x_all, P, P, save=torch.is_grad_enabled(),
+                                                                                split=P)
                 rgb_flat = self.rendering_network(points_flat, gradients_sdf, ray_dirs, feature_vectors, indices,
                                                   if_pixel_input=if_pixel_input, samples_per_ray=S)['rgb']
                 rgb = rgb_flat.reshape(-1, S, 3)
@@ -415,7 +422,7 @@ class MonoSDFNetwork(nn.Module):
             'weights': weights,
         }
         if self.training:
-            grad_theta = grad_all[P:]
+            grad_theta = grad_eik
             output['grad_theta'] = grad_theta[:grad_theta.shape[0] // 2]
             output['grad_theta_nei'] = grad_theta[grad_theta.shape[0] // 2:]
         output['normal_map'] = normal_map

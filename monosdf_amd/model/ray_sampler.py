@@ -39,6 +39,12 @@ class ErrorBoundSampler(RaySampler):
         z, z_eik, _ = self.sample(ray_dirs, cam_loc, model, want_points=False)
         return z, z_eik
 
+    @staticmethod
+    def _draw_columns(M, n, dev):
+        """n distinct columns of the dense sample set, the same for all rays: drawn on the CPU generator as the
+        reference does (ray_sampler.py:244) -- 256 bytes uploaded instead of a device sort."""
+        return torch.randperm(M)[:n].pin_memory().to(dev, non_blocking=True)
+
     def confirm(self):
         """After a speculative sample(): True if the convergence flags ask for exactly the rounds that were run."""
         if self._pending is None:
@@ -78,12 +84,21 @@ class ErrorBoundSampler(RaySampler):
         beta = torch.empty(N, **f32)
         flags = torch.zeros(2 * self.max_total_iters, device=dev, dtype=torch.int32)
         final_z = torch.empty(N, n_final, **f32)
-        jitter = u_final = None
+        jitter = u_final = nei_drawn = None
         if training:
+            # one launch for every U[0,1) draw of the call (stratified jitter, inverse-CDF u, neighbour jitter)
+            need = [k for k in ('jitter', 'final_u', 'nei_rand') if noise.get(k) is None]
+            sizes = {'jitter': N * n_eval, 'final_u': N * n_final, 'nei_rand': 6 * N if want_points else 0}
+            pool = torch.rand(sum(sizes[k] for k in need), **f32) if need else None
+            drawn, off = {}, 0
+            for k in need:
+                drawn[k] = pool[off:off + sizes[k]]
+                off += sizes[k]
             jitter = noise.get('jitter')
-            jitter = torch.rand(N, n_eval, **f32) if jitter is None else jitter.to(**f32).contiguous()
+            jitter = drawn['jitter'].view(N, n_eval) if jitter is None else jitter.to(**f32).contiguous()
             u_final = noise.get('final_u')
-            u_final = torch.rand(N, n_final, **f32) if u_final is None else u_final.to(**f32).contiguous()
+            u_final = drawn['final_u'].view(N, n_final) if u_final is None else u_final.to(**f32).contiguous()
+            nei_drawn = drawn.get('nei_rand')
         lemma = self._lemma
         a = _lib.SamplerArgs()
         a.ray_o, a.ray_d, a.N = cam_loc.data_ptr(), ray_dirs.data_ptr(), N
@@ -123,12 +138,12 @@ class ErrorBoundSampler(RaySampler):
                     eik_uniform = (torch.empty(N, 3, **f32).uniform_(-R, R) if eik_uniform is None
                                    else eik_uniform.to(**f32).contiguous())
                     nei = noise.get('nei_rand')
-                    nei = torch.rand(2 * N, 3, **f32) if nei is None else nei.to(**f32).contiguous()
+                    nei = nei_drawn.view(2 * N, 3) if nei is None else nei.to(**f32).contiguous()
                     a.eik_uniform, a.nei_rand = eik_uniform.data_ptr(), nei.data_ptr()
                     self._keep = (eik_uniform, nei)
             # the 32 extra columns for the one-round case (the common one); redrawn below if more rounds ran
             if n_extra > 0 and training and noise.get('extra_idx') is None:
-                extra_idx = torch.randperm(n_eval, device=dev)[:n_extra].contiguous()
+                extra_idx = self._draw_columns(n_eval, n_extra, dev)
 
         with torch.no_grad():
             while True:
@@ -161,8 +176,7 @@ class ErrorBoundSampler(RaySampler):
             if not training or noise.get('extra_idx') is not None or M != n_eval:
                 extra_idx = noise.get('extra_idx') if training else None
                 if extra_idx is None:
-                    # drawn on the device (the reference draws on the CPU generator; same distribution, no H2D copy)
-                    extra_idx = (torch.randperm(M, device=dev)[:n_extra] if training
+                    extra_idx = (self._draw_columns(M, n_extra, dev) if training
                                  else torch.linspace(0, M - 1, n_extra, device=dev).long())
             extra_idx = extra_idx.to(device=dev, dtype=torch.int64).contiguous()
         else:

@@ -255,11 +255,15 @@ def sdf_forward_nograd(mlp, wpack, bpack, x, aux, clamp_radius, sphere_scale):
 
 
 class SdfMlpFunction(torch.autograd.Function):
-    """(x, aux, W, b) -> (sdf [P,1], feat [n_feat,F], d sdf/dx [P,3], d sdf/d aux [P,A])."""
+    """(x, aux, W, b) -> (sdf [:n_split], sdf [n_split:], feat [n_feat,F], d sdf/dx [:n_split], d sdf/dx [n_split:],
+    d sdf/d aux [P,A]).  The two point groups (ray samples | eikonal points) come out as separate tensors --
+    views of one buffer -- because their gradients come from different consumers: joining them by slicing one
+    output would cost a zero-fill, a copy and an add per group in the backward pass."""
 
     @staticmethod
     def forward(ctx, x, aux, flat_w, flat_b, wpack, bpack, mlp, n_clamp, n_feat, clamp_radius,
-                sphere_scale, save):
+                sphere_scale, save, n_split=None):
+        ctx.set_materialize_grads(False)
         mp = mlp.mp
         plan = mlp.plan
         x = _need_cuda(x.detach(), 'points')
@@ -300,14 +304,13 @@ class SdfMlpFunction(torch.autograd.Function):
             _lib.call('msdf_sdf_fwd_grad', C.byref(plan), C.byref(a), _lib.stream_ptr())
         ctx.mlp, ctx.P, ctx.P_pad, ctx.n_feat, ctx.saved = mlp, P, P_pad, n_feat, save
         ctx.has_aux = has_aux
+        ctx.n_split = ns = P if n_split is None else int(n_split)
         ctx.save_for_backward(x, ws, clamped, wpack, bpack)
-        if has_aux:
-            return sdf, feat, nrm, r_aux
-        return sdf, feat, nrm, None
+        return sdf[:ns], sdf[ns:], feat, nrm[:ns], nrm[ns:], (r_aux if has_aux else None)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, g_sdf, g_feat, g_nrm, g_raux):
+    def backward(ctx, g_sdf, g_sdf_b, g_feat, g_nrm, g_nrm_b, g_raux):
         if not ctx.saved:
             raise RuntimeError('monosdf_amd: backward through an inference-mode SDF evaluation')
         x, ws, clamped, wpack, bpack = ctx.saved_tensors
@@ -318,10 +321,13 @@ class SdfMlpFunction(torch.autograd.Function):
         woff, _ = planlib.sdf_workspace(mp, P_pad)
         cont = lambda t: None if t is None else t.contiguous()
         g_sdf, g_feat, g_nrm, g_raux = cont(g_sdf), cont(g_feat), cont(g_nrm), cont(g_raux)
+        g_sdf_b, g_nrm_b = cont(g_sdf_b), cont(g_nrm_b)
         g_aux = torch.empty(P, 16 * plan.aux_tiles, device=dev, dtype=torch.float32) if ctx.has_aux else None
         b = _lib.BwArgs()
         b.wpack, b.bpack, b.x = wpack.data_ptr(), bpack.data_ptr(), x.data_ptr()
-        b.P, b.P_pad, b.n_feat = P, P_pad, ctx.n_feat
+        b.P, b.P_pad, b.n_feat, b.n_split = P, P_pad, ctx.n_feat, ctx.n_split
+        b.g_sdf_b = g_sdf_b.data_ptr() if g_sdf_b is not None else None
+        b.g_nrm_b = g_nrm_b.data_ptr() if g_nrm_b is not None else None
         b.g_sdf = g_sdf.data_ptr() if g_sdf is not None else None
         b.g_feat = g_feat.data_ptr() if (g_feat is not None and ctx.n_feat > 0) else None
         b.g_nrm = g_nrm.data_ptr() if g_nrm is not None else None
@@ -337,7 +343,7 @@ class SdfMlpFunction(torch.autograd.Function):
             grad = mlp.run_wgrad(P_pad, {'ws': ws})
         else:
             grad = torch.zeros(mp.n_w + mp.n_b, device=dev)
-        return (None, g_aux, grad[:mp.n_w], grad[mp.n_w:], None, None, None, None, None, None, None, None)
+        return (None, g_aux, grad[:mp.n_w], grad[mp.n_w:], None, None, None, None, None, None, None, None, None)
 
 
 # ---------------------------------------------------------------------------
@@ -426,6 +432,7 @@ class CompositeFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, sdf, rgb, nrm, beta, depth_scale, white_bkgd, bg, pose=None):
+        ctx.set_materialize_grads(False)      # unused outputs (e.g. `weights`) arrive as None, not as zero fills
         z = _need_cuda(z.detach(), 'z_vals')
         N, S = z.shape
         ctx.in_shapes = (sdf.shape, rgb.shape, nrm.shape)
