@@ -171,6 +171,7 @@ typedef struct {
   float* AB;               /* [absum * P_pad] */
   float* g_feat;           /* [P, 16*feat_tiles] */
   float* g_misc;           /* [P, 16*misc_tiles] */
+  float* g_nrm;            /* [P,3] or NULL: the normal columns of g_misc again, dense (mode idr) */
 } msdf_color_bwd_args_t;
 int msdf_color_backward(const msdf_plan_t* plan, const msdf_color_bwd_args_t* args, void* stream);
 

@@ -74,7 +74,7 @@ class ColorFwdArgs(C.Structure):
 class ColorBwdArgs(C.Structure):
     _fields_ = [('wpack', _P), ('bpack', _P), ('rgb', _P), ('g_rgb', _P),
                 ('P', C.c_int32), ('P_pad', C.c_int32), ('H', _P), ('AB', _P), ('g_feat', _P),
-                ('g_misc', _P)]
+                ('g_misc', _P), ('g_nrm', _P)]
 
 
 class CompositeArgs(C.Structure):

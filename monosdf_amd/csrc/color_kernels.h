@@ -180,6 +180,18 @@ __device__ __forceinline__ void color_backward_body(const msdf_plan_t& plan, con
 #pragma unroll
     for (int t = 0; t < 5; ++t)
       if (t < misc_tiles) *(v4f*)(a.g_misc + (size_t)pt * (16 * misc_tiles) + 16 * t + 4 * q) = acc[t];
+    if (a.g_nrm != nullptr && plan.mode == 1) {
+      // misc slots of mode idr: [x (3) | PE(view) (3 + 6 n_freqs) | normal (3)] -- the normal's gradient once more
+      // as a dense [P,3] row, so the caller does not have to copy the strided columns out
+      const int n0 = 3 + 3 + 6 * plan.n_freqs;
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = 16 * t + 4 * q + r - n0;
+          if (k >= 0 && k < 3) a.g_nrm[(size_t)pt * 3 + k] = acc[t][r];
+        }
+    }
   }
 }
 

@@ -422,9 +422,8 @@ class MonoSDFNetwork(nn.Module):
             'weights': weights,
         }
         if self.training:
-            grad_theta = grad_eik
-            output['grad_theta'] = grad_theta[:grad_theta.shape[0] // 2]
-            output['grad_theta_nei'] = grad_theta[grad_theta.shape[0] // 2:]
+            output['grad_theta'], output['grad_theta_nei'] = ops.SplitRowsFunction.apply(grad_eik,
+                                                                                          grad_eik.shape[0] // 2)
         output['normal_map'] = normal_map
         return output
 

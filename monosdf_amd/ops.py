@@ -412,12 +412,13 @@ class ColorMlpFunction(torch.autograd.Function):
         base = ws.data_ptr()
         b.H, b.AB = base + 4 * woff['H'], base + 4 * woff['AB']
         b.g_feat, b.g_misc = g_feat.data_ptr(), g_misc.data_ptr()
+        g_nrm = torch.empty(P, 3, device=dev, dtype=torch.float32) if plan.mode == 1 else None
+        b.g_nrm = g_nrm.data_ptr() if g_nrm is not None else None
         if P > 0:
             _lib.call('msdf_color_backward', C.byref(plan), C.byref(b), _lib.stream_ptr())
             grad = cmlp.run_wgrad(P_pad, {'ws': ws, 'feat': feat}, defer=USE_SIDE_STREAM)
         else:
             grad = torch.zeros(mp.n_w + mp.n_b, device=dev)
-        g_nrm = g_misc[:, mp.lead - 3:mp.lead].contiguous() if plan.mode == 1 else None
         g_code = None
         if ctx.has_code:
             g_code = g_misc[:, 48:].reshape(P // ctx.spr, ctx.spr, -1).sum(1)
@@ -628,6 +629,29 @@ class ProbeLossFunction(torch.autograd.Function):
 def probe_loss(out, w_normal=0.05, w_depth=0.1, w_eik=0.05, w_smooth=0.005):
     return ProbeLossFunction.apply(out['rgb_values'], out['normal_map'], out['depth_values'], out['grad_theta'],
                                    out['grad_theta_nei'], w_normal, w_depth, w_eik, w_smooth)
+
+
+class SplitRowsFunction(torch.autograd.Function):
+    """t -> (t[:k], t[k:]) whose backward is ONE concatenation (slicing twice costs two zero-fills, two copies
+    and an add in autograd)."""
+
+    @staticmethod
+    def forward(ctx, t, k):
+        ctx.set_materialize_grads(False)
+        ctx.k, ctx.shape = int(k), t.shape
+        return t[:k], t[k:]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, ga, gb):
+        if ga is None and gb is None:
+            return None, None
+        tail = ctx.shape[1:]
+        if ga is None:
+            ga = gb.new_zeros((ctx.k,) + tuple(tail))
+        if gb is None:
+            gb = ga.new_zeros((ctx.shape[0] - ctx.k,) + tuple(tail))
+        return torch.cat([ga, gb], 0), None
 
 
 class MonoSdfLossFunction(torch.autograd.Function):
