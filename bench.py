@@ -9,10 +9,14 @@ sampler 64/128/32; synthetic rays (origins U(-0.2,0.2)^3, unit directions) and r
 Weak scaling: every rank renders its own 1024-ray batch, gradients are averaged with one RCCL
 all-reduce of the flat 2.7 MB gradient, as the reference's DDP does.
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed inside the timed
-region) and `cpu_baseline` (the CPU oracle on a bounded sample, rank 0, N=1 only).  `value` is measured
-on the fp32 MFMA core (--precision fp32, the default); the same K steps are then repeated on the bf16x3
-core and reported under `alt_matrix_core` (never mixed into `value`).
+Every step renders a different one of 8 pre-generated ray batches.  Prints ONE JSON line (rank 0):
+`value` = the configs[1] training step at the random-init state (density beta 0.1, the sampler converges in one
+round) on the fp32 MFMA core, with `roofline` (dominant kernel, HIP-event timed inside the timed region;
+`traffic` read from the rocprofv3 PMC summary named beside it) and `cpu_baseline` (the CPU oracle per
+BASELINE.md section 3, rank 0, N=1 only).  Beside it, never mixed into `value` (N=1 only):
+`sharp_state` = the same step at density beta 0.01, where the sampler needs 2+ rounds, with the
+rounds per step and what the speculation of the round count cost; `hash_grid` = configs[2] with its HBM roofline;
+`alt_matrix_core` = the bf16x3 core.
 """
 import argparse
 import json
@@ -27,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_RAYS = 1024
+N_BATCHES = 8          # ray batches cycled through by the timed steps
 # entry points timed with HIP events inside the timed region (the kernels that make up >95 % of a step)
 TIMED = {'msdf_sdf_forward', 'msdf_sdf_fwd_grad', 'msdf_sdf_backward', 'msdf_wgrad', 'msdf_reduce',
          'msdf_color_forward', 'msdf_color_backward', 'msdf_hash_encode_forward', 'msdf_hash_encode_backward',
@@ -76,33 +81,79 @@ def sdf_macs_per_point():
     return 39 * 256 + 2 * 256 * 256 + 256 * 217 + 4 * 256 * 256 + 256 * 257
 
 
-def cpu_baseline(n_rays=256, iters=2):
-    """The CPU oracle (a port of the reference's PyTorch path, pinned by tests/golden) on a bounded sample."""
+def _cpu_time(n_rays, iters, threads):
     from oracle import config, monosdf_oracle as mo, synth
     conf = config.mlp_config()
     state = synth.make_state(conf, seed=0)
     rays = synth.make_rays(n_rays, seed=1)
     noise = synth.make_noise(conf, n_rays, 128, seed=2)
     idx = torch.arange(n_rays)
-    times = []
-    for it in range(iters + 1):
-        st = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in state.items()}
-        t0 = time.time()
-        out = mo.render(st, conf, rays, idx, True, True, noise)
-        mo.probe_loss(out).backward()
-        times.append(time.time() - t0)
-    dt = float(np.mean(times[1:]))
-    return {'value': n_rays / dt, 'unit': 'rays/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': '%d rays x 98 samples, fwd+bwd, %d timed iterations after 1 warm-up, fp32 PyTorch CPU oracle'
-                      % (n_rays, iters)}
+    before = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        times = []
+        for it in range(iters + 1):
+            st = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in state.items()}
+            t0 = time.time()
+            out = mo.render(st, conf, rays, idx, True, True, noise)
+            mo.probe_loss(out).backward()
+            times.append(time.time() - t0)
+    finally:
+        torch.set_num_threads(before)
+    return n_rays / float(np.mean(times[1:]))
 
 
-def grid_report(args, kern, dt, world, rounds, loss):
+def cpu_baseline():
+    """the CPU oracle (a port of the reference's PyTorch path, pinned by tests/golden) on
+    the configs[1] workload -- 1024 rays, 3 timed steady-state iterations on all host cores; plus the reference
+    runner's own setting of ONE thread (monosdf_train.py:37) on a bounded sample."""
+    cores = torch.get_num_threads()
+    return {'value': _cpu_time(N_RAYS, 3, cores), 'unit': 'rays/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d rays x 98 samples (the whole configs[1] batch), fwd+bwd, 3 timed iterations after 1 warm-up, '
+                      'fp32 PyTorch CPU oracle, sampler k=1' % N_RAYS,
+            'one_thread': {'value': _cpu_time(96, 1, 1), 'unit': 'rays/s', 'cores': 1,
+                           'sample': '96 rays x 98 samples, fwd+bwd, 1 timed iteration after 1 warm-up, '
+                                     'torch.set_num_threads(1) as the reference runner sets it'}}
+
+
+def pmc_traffic(entry, precision):
+    """HBM bytes per launch of `entry` from the committed rocprofv3 --pmc summary (FETCH_SIZE x2 + WRITE_SIZE per the
+    gfx950 note of MI355X_MICROARCH.md; scripts/pmc_sum.py) -> (bytes or None, file name or None)."""
+    kernel = entry + ('_k' if precision == 'fp32' else '_b16_k')
+    for name in ('r02_pmc_%s.json' % precision, 'r01_v8_pmc_%s.json' % precision):
+        path = os.path.join(ROOT, 'profiles', name)
+        if os.path.exists(path):
+            row = json.load(open(path)).get(kernel)
+            if row and 'hbm_bytes_per_launch_corrected' in row:
+                return row['hbm_bytes_per_launch_corrected'], 'profiles/' + name
+    return None, None
+
+
+def pmc_traffic_grid(entry):
+    kernels = {'msdf_hash_encode_forward': ['hg_forward_kernel'],
+               'msdf_hash_encode_backward': ['hg_scatter_kernel', 'hg_input_backward_kernel'],
+               'msdf_hash_encode_second_backward': ['hg_scatter_kernel', 'hg_second_grad_kernel']}
+    path = os.path.join(ROOT, 'profiles', 'r02_pmc_grid.json')
+    if not os.path.exists(path):
+        return None, None
+    table = json.load(open(path))
+    tot = 0.0
+    for k in kernels.get(entry, []):
+        row = next((v for name, v in table.items() if name.startswith(k)), None)
+        if row is None or 'hbm_bytes_per_launch_corrected' not in row:
+            return None, None
+        tot += row['hbm_bytes_per_launch_corrected']
+    return tot, 'profiles/r02_pmc_grid.json'
+
+
+def grid_report(args, kern, dt, world, rounds, loss, sampler):
     """configs[2]: roofline of the hash-grid entry points against HBM (SURVEY.md 8(d) bytes per point)."""
     P_main, P_smp = N_RAYS * 98 + 4 * N_RAYS, N_RAYS * 128
     # bytes per call of each entry point, summed over its launches in one step
     per_step_bytes = {
-        'msdf_hash_encode_forward': 1164.0 * P_smp * rounds + 1548.0 * P_main,     # sampler (no dy_dx) + main (dy_dx)
+        # main pass (with dy_dx) + one sampler evaluation (no dy_dx) per further launch of the step
+        'msdf_hash_encode_forward': 1548.0 * P_main + 1164.0 * P_smp * max(
+            0.0, kern.get('msdf_hash_encode_forward', {}).get('launches_per_step', 1.0 + rounds) - 1.0),
         'msdf_hash_encode_backward': 524.0 * P_main + 1164.0 * P_main,            # input-bwd (d/dx) + grid-bwd
         'msdf_hash_encode_second_backward': (524.0 + 1176.0) * P_main,
     }
@@ -117,9 +168,13 @@ def grid_report(args, kern, dt, world, rounds, loss):
         'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'configs[2]: multi-res hash grid 16 levels x 2 feats (2^19 entries/level), '
-                               '1024 rays x 98 samples, training step', 'sampler_rounds': rounds},
+                               '1024 rays x 98 samples, training step', 'sampler_rounds': sampler['rounds_per_step'],
+                   'ray_batches': N_BATCHES},
         'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': rows[dom]['algorithmic_GBps'], 'peak': 8000.0,
-                     'unit': 'GB/s', 'frac': rows[dom]['algorithmic_GBps'] / 8000.0, 'traffic': None},
+                     'unit': 'GB/s', 'frac': rows[dom]['algorithmic_GBps'] / 8000.0,
+                     'traffic': pmc_traffic_grid(dom)[0], 'traffic_source': pmc_traffic_grid(dom)[1],
+                     'note': 'parity of the hash-grid arithmetic is unpinned by reference outputs (CUDA-only in the '
+                             'reference, no vectors): checked against the restated oracle only'},
         'hash_entry_points': rows,
         'kernels_ms_per_step': {k: round(v['ms_per_step'], 4) for k, v in sorted(kern.items())},
         'loss': loss,
@@ -133,11 +188,16 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--config', choices=['mlp', 'grid'], default='mlp',
-                    help="mlp = BASELINE.json configs[1] (the headline metric); grid = configs[2] (hash-grid path)")
+                    help="mlp = BASELINE.json configs[1] (the headline metric); grid = configs[2] alone")
     ap.add_argument('--precision', choices=['fp32', 'bf16x3'], default=os.environ.get('MONOSDF_PRECISION', 'fp32'),
                     help='matrix core of the fused MLP kernels that `value` is measured on (default fp32 MFMA)')
     ap.add_argument('--no-alt-precision', dest='alt_precision', action='store_false',
-                    help='skip the second measurement on the other matrix core (reported under alt_matrix_core)')
+                    help='skip the measurement on the other matrix core (reported under alt_matrix_core)')
+    ap.add_argument('--no-extras', dest='extras', action='store_false',
+                    help='skip sharp_state and hash_grid (profiling runs want the headline workload only)')
+    ap.add_argument('--beta', type=float, default=0.1,
+                    help='density beta of the state `value` is measured at (0.1 = random init; profiling runs of the '
+                         'sharp state pass 0.01)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -158,38 +218,47 @@ def main():
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
-    def measure(precision):
+    def measure(precision, grid=False, beta=0.1):
         """W warm-up + K timed steps of the training step on the given matrix core; returns the max over ranks."""
         torch.manual_seed(0)                      # same initial weights on every rank (as DDP would broadcast)
-        model = MonoSDFNetwork(model_conf(grid=(args.config == 'grid'))).to(device).train()
+        model = MonoSDFNetwork(model_conf(grid=grid)).to(device).train()
         model.set_precision(precision)
+        with torch.no_grad():
+            model.density.beta.fill_(beta)
         params = [p for p in model.parameters() if p.requires_grad]
         try:
             opt = torch.optim.Adam(params, lr=5e-4, fused=True)      # one multi-tensor launch for the whole update
         except (RuntimeError, TypeError):
             opt = torch.optim.Adam(params, lr=5e-4)
+        averager = parallel.GradientAverager(params) if use_dist else None
         torch.manual_seed(1234 + rank)            # per-rank sampling noise
-        rays = make_rays(N_RAYS, 1 + rank, device)
+        # every rank cycles through its own 8 batches (weak scaling: no DistributedSampler in the reference)
+        batches = [make_rays(N_RAYS, 1 + 1000 * rank + b, device) for b in range(N_BATCHES)]
         indices = torch.arange(N_RAYS, device=device)
+        smp = model.ray_sampler
+        rounds_seen = []
 
-        def step():
+        def step(i):
             opt.zero_grad(set_to_none=True)
-            out = model(rays, indices, if_pixel_input=True)
+            out = model(batches[i % N_BATCHES], indices, if_pixel_input=True)
             loss = ops.probe_loss(out)        # the BASELINE.md probe loss, value + gradients in one HIP launch
             loss.backward()
-            parallel.average_gradients(params)        # one flat RCCL all-reduce (no-op on one GPU)
+            if averager is not None:
+                averager.average()            # one flat RCCL all-reduce of a persistent buffer
             opt.step()
+            rounds_seen.append(smp.last_rounds)
             return loss
 
-        for _ in range(args.warmup):
-            step()
-        rounds = model.ray_sampler.last_rounds
+        for i in range(args.warmup):
+            step(i)
+        del rounds_seen[:]
+        stats0 = dict(smp.stats)
         _lib.PROFILE = {}
         _lib.PROFILE_NAMES = TIMED
         barrier()
         t0 = time.time()
-        for _ in range(args.steps):
-            loss = step()
+        for i in range(args.steps):
+            loss = step(args.warmup + i)
         barrier()
         dt = time.time() - t0
         prof, _lib.PROFILE = _lib.PROFILE, None
@@ -204,7 +273,17 @@ def main():
             kern[name] = {'launches_per_step': len(ms) / args.steps, 'avg_ms': float(np.mean(ms)),
                           'ms_per_step': float(np.sum(ms)) / args.steps}
         plan = model.implicit_network._fused(device).mp.plan
-        return dict(dt=dt, kern=kern, rounds=rounds, loss=float(loss.item()), precision=precision,
+        hist = {}
+        for r in rounds_seen:
+            hist[str(r)] = hist.get(str(r), 0) + 1
+        d = {k: smp.stats[k] - stats0[k] for k in stats0}
+        sampler = {'rounds_per_step': hist, 'mean_rounds': float(np.mean(rounds_seen)),
+                   # the round count of a step is guessed from the last steps so that the host never waits for the
+                   # device inside a step: `repeated_passes` = steps whose guess was too small (the forward pass ran
+                   # twice), `idle_rounds` = rounds enqueued beyond the ones that ran (one SDF evaluation of 131,072
+                   # points each, results unused)
+                   'repeated_passes': d['repeats'], 'idle_rounds': d['idle_rounds'], 'beta0': beta + 1e-4}
+        return dict(dt=dt, kern=kern, rounds=hist, sampler=sampler, loss=float(loss.item()), precision=precision,
                     slots=(plan.hsum, plan.qsum, plan.absum))
 
     def mlp_rooflines(m):
@@ -224,32 +303,40 @@ def main():
             'msdf_sdf_fwd_grad': 4.0 * P * (3 * hs),               # H written, H re-read, PM written
             'msdf_sdf_backward': 4.0 * P * (5 * hs + qs + ab),     # H x2, PM, T read; T, QB, AB written
         }
-        dom = max((n for n in kern if n in flops), key=lambda n: kern[n]['ms_per_step'])
+        # dominant = the largest per-LAUNCH duration among the kernels with a FLOP model (the sampler's forward
+        # kernel runs once per round; per launch it is the smallest of the three)
+        dom = max((n for n in kern if n in flops), key=lambda n: kern[n]['avg_ms'])
         t = kern[dom]['avg_ms'] * 1e-3
+        traffic, source = pmc_traffic(dom, m['precision'])
         mf = {'bound': 'mfma', 'kernel': dom, 'achieved': flops[dom] / t / 1e12, 'peak': F32_MFMA_PEAK_TFLOPS,
-              'unit': 'TFLOP/s', 'frac': flops[dom] / t / 1e12 / F32_MFMA_PEAK_TFLOPS, 'traffic': None,
-              'avg_kernel_ms': kern[dom]['avg_ms']}
-        # rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE per launch of the same command,
-        # profiles/r01_v8_pmc_{fp32,bf16x3}.json (separate passes; the kernels' data movement is fixed by P)
-        measured = {'fp32': {'msdf_sdf_backward': 6.650e9, 'msdf_sdf_fwd_grad': 2.937e9, 'msdf_sdf_forward': 2.3e7},
-                    'bf16x3': {'msdf_sdf_backward': 6.503e9, 'msdf_sdf_fwd_grad': 3.061e9, 'msdf_sdf_forward': 1.05e8}}
-        mf['traffic'] = measured[m['precision']].get(dom)
+              'unit': 'TFLOP/s', 'frac': flops[dom] / t / 1e12 / F32_MFMA_PEAK_TFLOPS, 'traffic': traffic,
+              'traffic_source': source, 'avg_kernel_ms': kern[dom]['avg_ms']}
         hb = None
         if dom in hbm:
             hb = {'bound': 'hbm', 'kernel': dom, 'achieved': hbm[dom] / t / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
-                  'frac': hbm[dom] / t / 1e9 / 8000.0, 'traffic': mf['traffic'], 'avg_kernel_ms': kern[dom]['avg_ms']}
+                  'frac': hbm[dom] / t / 1e9 / 8000.0, 'traffic': traffic, 'traffic_source': source,
+                  'avg_kernel_ms': kern[dom]['avg_ms']}
         return mf, hb
 
-    primary = measure(args.precision)
-    alt = None
-    if args.alt_precision and args.config == 'mlp':
-        alt = measure('bf16x3' if args.precision == 'fp32' else 'fp32')
+    def ms(m):
+        return {k: round(v['ms_per_step'], 4) for k, v in sorted(m['kern'].items())}
+
+    def rate(m):
+        return world * N_RAYS * args.steps / m['dt']
+
+    grid_only = args.config == 'grid'
+    primary = measure(args.precision, grid=grid_only, beta=args.beta)
+    single = world == 1 and not use_dist
+    extras = args.extras and single and not grid_only
+    sharp = measure(args.precision, beta=0.01) if extras else None
+    alt = measure('bf16x3' if args.precision == 'fp32' else 'fp32') if (extras and args.alt_precision) else None
+    grid = measure('fp32', grid=True) if extras else None
 
     if rank == 0:
-        kern, dt, rounds = primary['kern'], primary['dt'], primary['rounds']
         dtype = 'f32' if args.precision == 'fp32' else 'bf16x3 (fp32 split into 2 bf16, fp32 accumulate)'
-        if args.config == 'grid':
-            res = grid_report(args, kern, dt, world, rounds, primary['loss'])
+        if grid_only:
+            res = grid_report(args, primary['kern'], primary['dt'], world, primary['sampler']['mean_rounds'],
+                              primary['loss'], primary['sampler'])
             res['dtype'] = dtype
             print(json.dumps(res))
             if use_dist:
@@ -258,30 +345,45 @@ def main():
         mf, hb = mlp_rooflines(primary)
         res = {
             'metric': 'rays/sec fwd+bwd, 1024 rays x 98 samples, 8x256 SDF MLP',
-            'value': world * N_RAYS * args.steps / dt, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
+            'value': rate(primary), 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1e3 * primary['dt'] / args.steps, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
             'config': {'workload': 'configs[1]: 1024 rays x 98 samples per GPU, ImplicitNetwork 8x256 + '
-                                   'RenderingNetwork 289-256-256-3, error-bounded sampler (k=%d round), '
-                                   'training step = fwd + loss + bwd + Adam' % rounds,
-                       'rays_per_gpu': N_RAYS, 'samples_per_ray': 98, 'sampler_rounds': rounds,
-                       'matrix_core': args.precision},
+                                   'RenderingNetwork 289-256-256-3, error-bounded sampler, random-init weights '
+                                   '(density beta %g), training step = fwd + loss + bwd + Adam, a different one of '
+                                   '%d ray batches every step' % (args.beta, N_BATCHES),
+                       'rays_per_gpu': N_RAYS, 'samples_per_ray': 98, 'sampler_rounds': primary['rounds'],
+                       'ray_batches': N_BATCHES, 'matrix_core': args.precision},
             'roofline': mf if args.precision == 'fp32' else (hb or mf),
-            'kernels_ms_per_step': {k: round(v['ms_per_step'], 4) for k, v in sorted(kern.items())},
+            'sampler': primary['sampler'],
+            'kernels_ms_per_step': ms(primary),
             'loss': primary['loss'],
         }
+        if sharp is not None:
+            smf, shb = mlp_rooflines(sharp)
+            res['sharp_state'] = {
+                'what': 'the same training step with density beta = 0.01 (SURVEY 8(d) "sharpened" state): the sampler '
+                        'needs 2+ rounds, each one more SDF evaluation of 131,072 points',
+                'value': rate(sharp), 'unit': 'rays/s', 'ms_per_step': 1e3 * sharp['dt'] / args.steps,
+                'sampler': sharp['sampler'], 'roofline': smf if args.precision == 'fp32' else (shb or smf),
+                'kernels_ms_per_step': ms(sharp)}
+        if grid is not None:
+            g = grid_report(args, grid['kern'], grid['dt'], world, grid['sampler']['mean_rounds'], grid['loss'],
+                            grid['sampler'])
+            res['hash_grid'] = {k: g[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'config', 'roofline',
+                                                  'hash_entry_points', 'kernels_ms_per_step')}
         if alt is not None:
             amf, ahb = mlp_rooflines(alt)
             other = 'bf16x3' if args.precision == 'fp32' else 'fp32'
             res['alt_matrix_core'] = {
-                'matrix_core': other, 'value': world * N_RAYS * args.steps / alt['dt'], 'unit': 'rays/s',
+                'matrix_core': other, 'value': rate(alt), 'unit': 'rays/s',
                 'ms_per_step': 1e3 * alt['dt'] / args.steps,
                 'roofline': (ahb or amf) if other == 'bf16x3' else amf,
-                'kernels_ms_per_step': {k: round(v['ms_per_step'], 4) for k, v in sorted(alt['kern'].items())},
-                'note': 'same workload, steps and warm-up on the other matrix core of the fused MLP kernels; both '
-                        'pass the same parity tests (tests/test_gpu_parity.py); `value` above is the %s core' % args.precision,
+                'kernels_ms_per_step': ms(alt),
+                'note': 'same workload, steps and warm-up on the other matrix core of the fused MLP kernels (opt-in: '
+                        'narrower arithmetic than the reference); `value` above is the %s core' % args.precision,
             }
-        if world == 1 and not args.no_cpu_baseline:
+        if single and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline()
         print(json.dumps(res))
     if use_dist:

@@ -49,7 +49,7 @@ extern "C" {
 #define MSDF_ERR_LAUNCH 2
 #define MSDF_ERR_UNSUPPORTED 3
 
-#define MSDF_ABI_VERSION 3
+#define MSDF_ABI_VERSION 4
 int msdf_abi_version(void);
 
 /* ---- hash grid (reference: hashencoder/src/hashencoder.h:13-15) ---- */
@@ -65,6 +65,29 @@ int msdf_hash_encode_second_backward(const float* grad, const float* inputs, con
                                      uint32_t H, int calc_grad_inputs, const float* dy_dx,
                                      const float* grad_grad_inputs, float* grad_grad, float* grad2_embeddings,
                                      void* stream);
+
+/* The same two gradients with the embedding scatter summed per table slice in LDS instead of one memory-side float
+ * atomic per corner (csrc/hashgrid.hip "Binned scatter"): the argument lists above, followed by the number of rows of
+ * the embedding table and a caller-owned DEVICE workspace of at least msdf_hash_scatter_workspace_bytes() bytes
+ * (16-byte aligned; contents are scratch, nothing persists between calls).  Results equal the plain entry points up
+ * to the order of the fp32 sums. */
+int64_t msdf_hash_scatter_workspace_bytes(uint32_t B, uint32_t C, uint32_t L, uint64_t n_entries);
+int msdf_hash_encode_backward_ws(const float* grad, const float* inputs, const float* embeddings, const int* offsets,
+                                 float* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                 uint32_t H, int calc_grad_inputs, const float* dy_dx, float* grad_inputs,
+                                 uint64_t n_entries, void* workspace, uint64_t workspace_bytes, void* stream);
+int msdf_hash_encode_second_backward_ws(const float* grad, const float* inputs, const float* embeddings,
+                                        const int* offsets, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                        uint32_t H, int calc_grad_inputs, const float* dy_dx,
+                                        const float* grad_grad_inputs, float* grad_grad, float* grad2_embeddings,
+                                        uint64_t n_entries, void* workspace, uint64_t workspace_bytes, void* stream);
+/* Both embedding gradients of a training step in one scatter (they visit the same corners): grad_embeddings +=
+ * what msdf_hash_encode_backward adds for `grad_first` plus what msdf_hash_encode_second_backward adds for
+ * (`grad_second`, grad_grad_inputs).  grad_first / grad_second: [L,B,C]. */
+int msdf_hash_encode_backward_fused(const float* grad_first, const float* grad_second, const float* inputs,
+                                    const int* offsets, float* grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
+                                    uint32_t L, float S, uint32_t H, const float* grad_grad_inputs,
+                                    uint64_t n_entries, void* workspace, uint64_t workspace_bytes, void* stream);
 
 /* ---- fused MLPs ----
  * Every entry point that takes a plan runs on the matrix core named by plan->precision (monosdf_plan.h):
@@ -176,8 +199,8 @@ typedef struct {
 int msdf_color_backward(const msdf_plan_t* plan, const msdf_color_bwd_args_t* args, void* stream);
 
 /* wg_map_dev: int32 pairs (item, split) for each of the n_wgs workgroups (balanced by the host) */
-int msdf_wgrad(const msdf_wgrad_item_t* items_dev, const int32_t* wg_map_dev, int n_wgs, const float* workspace,
-               float* partials, int P_pad, int precision /* MSDF_PRECISION_* */, void* stream);
+int msdf_wgrad(const msdf_wgrad_item_t* items_dev, const int32_t* wg_map_dev, int n_wgs, float* partials,
+               int P_pad, int precision /* MSDF_PRECISION_* */, void* stream);
 int msdf_reduce(const msdf_reduce_rule_t* rules_dev, int n_rules, const int* maps_dev, const float* partials,
                 float* dst, void* stream);
 
@@ -291,22 +314,44 @@ typedef struct {
   int32_t* new_pos;          /* [N, n_eval] their positions in z */
   float* pts;                /* [N * n_eval, 3] their 3-D points */
   float* beta;               /* [N] */
-  uint32_t* flag;            /* [2] for this round: max beta bits, decision (1 = another round) */
+  uint32_t* flags;           /* [2 * max_rounds], zeroed by the caller before the first round: flags[2r] = bits of the
+                                batch's max beta after round r, flags[2r+1] = 1 when round r asks for another one.
+                                Rounds r > 0 return at once unless flags[2(r-1)+1] is set, so enqueueing more rounds
+                                than needed is harmless (reference: ray_sampler.py:125,179). */
   const float* jitter;       /* [N, n_eval] or NULL (eval) */
   const float* u_final;      /* [N, n_final] or NULL */
   float* final_z;            /* [N, n_final] */
-  const int64_t* extra_idx;  /* [n_extra] columns of z to add to the final set */
+  const int64_t* extra_idx;  /* [max_rounds, n_extra]: row k-1 = the columns of the dense set to add to the final set
+                                when k rounds ran (the kernel reads k from `flags`; reference: ray_sampler.py:242-247) */
   const int64_t* eik_idx;    /* [N] or NULL */
   float* z_out;              /* [N, n_final + n_extra + 2] */
   float* z_eik;              /* [N] or NULL */
   float* pts_out;            /* [N * S (+ 4 N), 3] or NULL: ray samples, then (training) the eikonal points */
   const float* eik_uniform;  /* [N,3] uniform points in the bounding cube, or NULL (no eikonal block) */
   const float* nei_rand;     /* [2N,3] U[0,1) jitter of the neighbour points (reference network.py:583-594) */
+  float* far_out;            /* [N] or NULL: msdf_sampler_init also returns the far bound of the uniform samples */
+  int32_t* rounds_out;       /* [1] or NULL: msdf_sampler_finish writes the number of rounds that ran */
+  float* dbg_dstar;          /* [N, m_max] or NULL: msdf_sampler_beta writes d* of the M-1 intervals (tests) */
+  float* dbg_err0;           /* [N] or NULL: msdf_sampler_beta writes the error bound at beta0 (tests) */
+  float* dbg_cdf;            /* [N, m_max] or NULL: msdf_sampler_resample writes the cdf it inverts (tests) */
 } msdf_sampler_args_t;
 int msdf_sampler_init(const msdf_sampler_args_t* args, void* stream);
 int msdf_sampler_beta(const msdf_sampler_args_t* args, void* stream);
 int msdf_sampler_resample(const msdf_sampler_args_t* args, void* stream);
 int msdf_sampler_finish(const msdf_sampler_args_t* args, void* stream);
+
+/* ErrorBoundSampler.get_error_bound (reference: model/ray_sampler.py:264-272): z [N,M] sorted, sdf [N,M],
+ * dstar [N,M-1], beta [N] (beta_stride 1) or [1] (beta_stride 0) -> out [N] = max opacity error bound per ray. */
+int msdf_sampler_error_bound(const float* z, const float* sdf, const float* dstar, const float* beta,
+                             int beta_stride, int N, int M, float* out, void* stream);
+
+/* LaplaceDensity.density_func (reference: model/density.py:21-26) on n values laid out in rows of `cols`;
+ * beta [1] (beta_stride 0) or one per row (beta_stride 1).  The backward returns d/d sdf and the per-element
+ * d/d beta terms (the caller sums them per beta). */
+int msdf_laplace_density(const float* sdf, const float* beta, int beta_stride, int64_t n, int cols, float* out,
+                         void* stream);
+int msdf_laplace_density_backward(const float* sdf, const float* beta, int beta_stride, int64_t n, int cols,
+                                  const float* g, float* g_sdf, float* g_beta_elem, void* stream);
 
 /* ---- ray generation (reference: utils/rend_util.py:63-91,105-118 as called at
  * model/network.py:505-516).  uv [n,2] pixel coordinates, pose [4,4] camera-to-world, intrinsics [4,4];

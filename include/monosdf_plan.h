@@ -62,10 +62,13 @@ typedef struct {
 } msdf_packrule_t;
 
 /* one weight-gradient work item: PART[split] = sum_{p in split} X[p][0:wx]^T Y[p][0:wy]
- * (+ optional column sums of X, + optional sum_p v[p] Y[p][:]).  Offsets are in floats
- * relative to the workspace / the partial buffer. */
+ * (+ optional column sums of X, + optional sum_p v[p] Y[p][:]).  X / Y / v are device pointers (the operands of
+ * one launch live in different buffers: the saved activations, the feature tensor); the *_off fields are float
+ * offsets into the partial buffer. */
 typedef struct {
-  int64_t x_off, y_off, v_off;  /* v_off < 0: none */
+  const float* x;               /* [P_pad, x_ld] */
+  const float* y;               /* [P_pad, y_ld] */
+  const float* v;               /* [P_pad] or NULL */
   int64_t part_off;             /* [n_splits][wx*wy] */
   int64_t colsum_off;           /* [n_splits][wx] or < 0 */
   int64_t vrow_off;             /* [n_splits][wy] or < 0 */

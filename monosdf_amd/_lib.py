@@ -33,7 +33,7 @@ class PackRule(C.Structure):
 
 
 class WgradItem(C.Structure):
-    _fields_ = [('x_off', C.c_int64), ('y_off', C.c_int64), ('v_off', C.c_int64),
+    _fields_ = [('x', C.c_void_p), ('y', C.c_void_p), ('v', C.c_void_p),
                 ('part_off', C.c_int64), ('colsum_off', C.c_int64), ('vrow_off', C.c_int64),
                 ('x_ld', C.c_int32), ('y_ld', C.c_int32), ('wx', C.c_int32), ('wy', C.c_int32),
                 ('n_splits', C.c_int32), ('pad_', C.c_int32)]
@@ -121,9 +121,10 @@ class SamplerArgs(C.Structure):
                 ('beta_iters', C.c_int32), ('near', C.c_float), ('far', C.c_float), ('bound', C.c_float),
                 ('eps', C.c_float), ('add_tiny', C.c_float), ('lemma', C.c_float),
                 ('beta0', _P), ('z', _P), ('sdf', _P), ('new_z', _P), ('new_sdf', _P), ('new_pos', _P),
-                ('pts', _P), ('beta', _P), ('flag', _P), ('jitter', _P), ('u_final', _P), ('final_z', _P),
+                ('pts', _P), ('beta', _P), ('flags', _P), ('jitter', _P), ('u_final', _P), ('final_z', _P),
                 ('extra_idx', _P), ('eik_idx', _P), ('z_out', _P), ('z_eik', _P), ('pts_out', _P),
-                ('eik_uniform', _P), ('nei_rand', _P)]
+                ('eik_uniform', _P), ('nei_rand', _P), ('far_out', _P), ('rounds_out', _P),
+                ('dbg_dstar', _P), ('dbg_err0', _P), ('dbg_cdf', _P)]
 
 
 _ERR = {1: 'invalid argument', 2: 'kernel launch failed', 3: 'unsupported configuration'}
@@ -137,6 +138,14 @@ _SIGNATURES = {
                                   C.c_float, C.c_uint32, C.c_int, _P, _P, _P],
     'msdf_hash_encode_second_backward': [_P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32,
                                          C.c_uint32, C.c_float, C.c_uint32, C.c_int, _P, _P, _P, _P, _P],
+    'msdf_hash_scatter_workspace_bytes': [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64],
+    'msdf_hash_encode_backward_ws': [_P, _P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                     C.c_float, C.c_uint32, C.c_int, _P, _P, C.c_uint64, _P, C.c_uint64, _P],
+    'msdf_hash_encode_second_backward_ws': [_P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                            C.c_float, C.c_uint32, C.c_int, _P, _P, _P, _P, C.c_uint64, _P,
+                                            C.c_uint64, _P],
+    'msdf_hash_encode_backward_fused': [_P, _P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                        C.c_float, C.c_uint32, _P, C.c_uint64, _P, C.c_uint64, _P],
     'msdf_weightnorm_forward': [_P, _P, C.c_int, _P, _P, _P, _P],
     'msdf_weightnorm_backward': [_P, _P, C.c_int, _P, _P, _P, _P, _P],
     'msdf_pack_weights': [C.POINTER(Plan), _P, _P, _P, _P, _P, _P, _P],
@@ -145,7 +154,7 @@ _SIGNATURES = {
     'msdf_sdf_backward': [C.POINTER(Plan), C.POINTER(BwArgs), _P],
     'msdf_color_forward': [C.POINTER(Plan), C.POINTER(ColorFwdArgs), _P],
     'msdf_color_backward': [C.POINTER(Plan), C.POINTER(ColorBwdArgs), _P],
-    'msdf_wgrad': [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, _P],
+    'msdf_wgrad': [_P, _P, C.c_int, _P, C.c_int, C.c_int, _P],
     'msdf_camera_rays': [_P, _P, _P, C.c_int, _P, _P, _P, _P],
     'msdf_monosdf_loss': [C.POINTER(MonoSdfLossArgs), _P],
     'msdf_reduce': [_P, C.c_int, _P, _P, _P, _P],
@@ -156,7 +165,12 @@ _SIGNATURES = {
     'msdf_sampler_beta': [C.POINTER(SamplerArgs), _P],
     'msdf_sampler_resample': [C.POINTER(SamplerArgs), _P],
     'msdf_sampler_finish': [C.POINTER(SamplerArgs), _P],
+    'msdf_sampler_error_bound': [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P],
+    'msdf_laplace_density': [_P, _P, C.c_int, C.c_int64, C.c_int, _P, _P],
+    'msdf_laplace_density_backward': [_P, _P, C.c_int, C.c_int64, C.c_int, _P, _P, _P, _P],
 }
+
+ABI_VERSION = 4
 
 _lib = None
 
@@ -174,8 +188,8 @@ def load():
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name)        # AttributeError if the symbol is missing: intended
         fn.argtypes = argtypes
-        fn.restype = C.c_int
-    if lib.msdf_abi_version() != 3:
+        fn.restype = C.c_int64 if name.endswith('_bytes') else C.c_int
+    if lib.msdf_abi_version() != ABI_VERSION:
         raise RuntimeError('monosdf_amd: ABI version mismatch, rebuild the library')
     _lib = lib
     return lib

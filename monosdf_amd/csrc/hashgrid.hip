@@ -292,6 +292,341 @@ static int hg_launch_scatter(const float* grad, const float* inputs, const int* 
   return MSDF_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Binned scatter: the same sums WITHOUT one memory-side atomic per corner.
+//
+// The direct kernels above issue B * L * 8 scattered float-atomic requests per call; the memory-side atomic units
+// retire ~20 G requests/s whatever the schedule (MI355X_MICROARCH.md "Global float atomics": one 64-B request per
+// distinct row), which is where they sit (0.59 ms for the 14 fine levels at B = 104,448).  Here every level's table
+// is cut into slices of HB_SLICE_FLOATS floats (one LDS accumulator), and
+//   hb_count_k       counts the corner contributions per (level, slice) bin      [LDS histogram per workgroup]
+//   hb_scan_k        turns the counts into bin offsets and a list of work items  [one workgroup]
+//   hb_place_k       writes each contribution as a record {entry in slice, C values} into its bin
+//   hb_accumulate_k  one workgroup per bin (or per HB_CHUNK records of a crowded bin) sums its records into LDS
+//                    with ds_add_f32 and adds the slice to the table once: plain read-modify-write when the
+//                    bin has one workgroup, contiguous float atomics (the fast shape) when it has several.
+// Coarse levels (hundreds of contributions per entry) and fine hashed levels (mostly unique entries) take the same
+// path; the records are the only extra traffic (B * L * 8 * (4 + 4 C) bytes written once, read once).
+// The sum order inside a bin follows the order in which workgroups reserved their runs: like the atomics it replaces
+// it is not fixed from run to run (differences at fp32 rounding).
+// ---------------------------------------------------------------------------
+#define HB_SLICE_FLOATS 8192
+#define HB_CHUNK 8192
+#define HB_THREADS 256
+#define HB_PTS 4                      // points per thread in the count / place kernels (1,024 per workgroup)
+#define HB_MAX_SLICES 1024            // per level, in the LDS histogram (2^19 entries x C = 8 -> 512)
+#define HB_HDR_INTS 16
+
+struct HbLayout {                      // int32 offsets into the workspace
+  int nb_max, work_max, slice_base, bin_count, bin_base, bin_cursor, work, hdr_ints;
+  size_t rec_off_bytes, total_bytes;
+};
+static HbLayout hb_layout(const uint32_t B, const uint32_t C, const uint32_t L, const uint64_t n_entries) {
+  HbLayout y;
+  y.nb_max = (int)((n_entries * C + HB_SLICE_FLOATS - 1) / HB_SLICE_FLOATS + L);
+  y.work_max = y.nb_max + (int)(((uint64_t)B * L * 8 + HB_CHUNK - 1) / HB_CHUNK);
+  y.slice_base = HB_HDR_INTS;
+  y.bin_count = y.slice_base + (int)L + 1;
+  y.bin_base = y.bin_count + y.nb_max;
+  y.bin_cursor = y.bin_base + y.nb_max + 1;
+  y.work = (y.bin_cursor + y.nb_max + 3) & ~3;          // int4 descriptors, 16-byte aligned
+  y.hdr_ints = y.work + 4 * y.work_max;
+  y.rec_off_bytes = (((size_t)y.hdr_ints * 4) + 255) & ~(size_t)255;
+  y.total_bytes = y.rec_off_bytes + (size_t)B * L * 8 * (4 + 4 * C);
+  return y;
+}
+
+__global__ void __launch_bounds__(HB_THREADS)
+hb_setup_k(int* __restrict__ ws, const HbLayout y, const int* __restrict__ offsets, const uint32_t L, const uint32_t C) {
+  for (int i = threadIdx.x; i < y.nb_max; i += HB_THREADS) ws[y.bin_count + i] = 0;
+  if (threadIdx.x == 0) {
+    const uint32_t epb = HB_SLICE_FLOATS / C;
+    int base = 0;
+    for (uint32_t l = 0; l < L; ++l) {
+      ws[y.slice_base + l] = base;
+      const uint32_t hsize = (uint32_t)(offsets[l + 1] - offsets[l]);
+      base += (int)((hsize + epb - 1) / epb);
+    }
+    ws[y.slice_base + L] = base;
+    ws[0] = base;                      // number of bins in use
+  }
+}
+
+template <int C>
+__global__ void __launch_bounds__(HB_THREADS)
+hb_count_k(const float* __restrict__ inputs, const int* __restrict__ offsets, int* __restrict__ ws, const HbLayout y,
+           const uint32_t B, const float S, const uint32_t H) {
+  __shared__ int hist[HB_MAX_SLICES];
+  const uint32_t level = blockIdx.y;
+  const int sb = ws[y.slice_base + level];
+  const int ns = ws[y.slice_base + level + 1] - sb;
+  const bool local = ns <= HB_MAX_SLICES;
+  if (local) {
+    for (int i = threadIdx.x; i < ns; i += HB_THREADS) hist[i] = 0;
+    __syncthreads();
+  }
+  constexpr uint32_t epb = HB_SLICE_FLOATS / C;
+  const HgLevel lv = hg_level(offsets, level, S, H);
+#pragma unroll
+  for (int p = 0; p < HB_PTS; ++p) {
+    const uint32_t b = (blockIdx.x * HB_PTS + p) * HB_THREADS + threadIdx.x;
+    if (b >= B) continue;
+    const HgCell c = hg_locate(inputs, lv, b);
+    if (c.oob) continue;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t idx = hg_index(c.gx + (k & 1), c.gy + ((k >> 1) & 1), c.gz + ((k >> 2) & 1), c.hsize, c.res);
+      const int s = (int)(idx / epb);
+      if (local) atomicAdd(&hist[s], 1);
+      else atomicAdd(&ws[y.bin_count + sb + s], 1);
+    }
+  }
+  if (local) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < ns; i += HB_THREADS) {
+      const int n = hist[i];
+      if (n) atomicAdd(&ws[y.bin_count + sb + i], n);
+    }
+  }
+}
+
+// exclusive scans over the bins: record offsets, and the list of work items for hb_accumulate_k -- one per
+// HB_CHUNK records of a bin: {first record, end record, first float of the slice in the table, floats | shared flag}
+__global__ void __launch_bounds__(1024)
+hb_scan_k(int* __restrict__ ws, const HbLayout y, const int* __restrict__ offsets, const uint32_t L, const uint32_t C) {
+  __shared__ int part[1024], partw[1024];
+  const int nb = ws[0];
+  const int t = threadIdx.x;
+  const int per = (nb + 1023) / 1024;
+  const int lo = min(nb, t * per), hi = min(nb, lo + per);
+  int s = 0, w = 0;
+  for (int i = lo; i < hi; ++i) {
+    const int n = ws[y.bin_count + i];
+    s += n;
+    w += (n + HB_CHUNK - 1) / HB_CHUNK;
+  }
+  part[t] = s; partw[t] = w;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {            // Hillis-Steele inclusive scan of the per-thread totals
+    const int a = (t >= d) ? part[t - d] : 0, aw = (t >= d) ? partw[t - d] : 0;
+    __syncthreads();
+    part[t] += a; partw[t] += aw;
+    __syncthreads();
+  }
+  int run = part[t] - s, runw = partw[t] - w;
+  const uint32_t epb = HB_SLICE_FLOATS / C;
+  int level = 0;
+  for (int i = lo; i < hi; ++i) {
+    const int n = ws[y.bin_count + i];
+    ws[y.bin_base + i] = run;
+    ws[y.bin_cursor + i] = run;
+    while (level + 1 < (int)L && ws[y.slice_base + level + 1] <= i) ++level;
+    const uint32_t e0 = (uint32_t)(i - ws[y.slice_base + level]) * epb;
+    const uint32_t hsize = (uint32_t)(offsets[level + 1] - offsets[level]);
+    const int nf = (int)(min(epb, hsize - e0) * C);
+    const int chunks = (n + HB_CHUNK - 1) / HB_CHUNK;
+    for (int c = 0; c < chunks; ++c) {
+      int* d = ws + y.work + 4 * (runw + c);
+      d[0] = run + c * HB_CHUNK;
+      d[1] = min(run + n, run + (c + 1) * HB_CHUNK);
+      d[2] = (int)(((uint32_t)offsets[level] + e0) * C);   // < 2^31 floats: tables of up to 8 GB
+      d[3] = nf | (chunks > 1 ? (int)0x40000000 : 0);
+    }
+    run += n;
+    runw += chunks;
+  }
+  if (t == 1023) {
+    ws[y.bin_base + nb] = part[1023];
+    ws[1] = partw[1023];               // number of work items
+  }
+}
+
+// MODE 0: w_k * grad  (kernel_grid_backward);  MODE 1: second-order coefficient * grad
+// (kernel_grid_second_backward_embedding);  MODE 2: w_k * grad + coefficient * grad2, both in one pass.
+// A workgroup takes 1,024 points of one level: phase 1 ranks every corner inside (workgroup, bin) with an LDS
+// histogram, one returning global atomic per non-empty bin then reserves the workgroup's run in the bin, phase 2
+// writes the records.  (index in level | rank << 19) is all that is kept per corner between the phases.
+template <int C, int MODE>
+__global__ void __launch_bounds__(HB_THREADS)
+hb_place_k(const float* __restrict__ grad, const float* __restrict__ grad2, const float* __restrict__ inputs,
+           const int* __restrict__ offsets, const float* __restrict__ gg_inputs, int* __restrict__ ws,
+           const HbLayout y, const uint32_t B, const float S, const uint32_t H) {
+  __shared__ int hist[HB_MAX_SLICES];
+  const uint32_t level = blockIdx.y;
+  const int sb = ws[y.slice_base + level];
+  const int ns = ws[y.slice_base + level + 1] - sb;
+  const HgLevel lv = hg_level(offsets, level, S, H);
+  // packed (index | rank << 19) needs index < 2^19 and rank < 2^13 (8 * 1,024 records per workgroup)
+  const bool local = ns <= HB_MAX_SLICES && lv.hsize <= (1u << 19);
+  if (local) {
+    for (int i = threadIdx.x; i < ns; i += HB_THREADS) hist[i] = 0;
+    __syncthreads();
+  }
+  constexpr uint32_t epb = HB_SLICE_FLOATS / C;
+  uint32_t packed[HB_PTS][8];
+  uint32_t live = 0;
+#pragma unroll
+  for (int p = 0; p < HB_PTS; ++p) {
+    const uint32_t b = (blockIdx.x * HB_PTS + p) * HB_THREADS + threadIdx.x;
+    if (b >= B) continue;
+    const HgCell c = hg_locate(inputs, lv, b);
+    if (c.oob) continue;
+    live |= 1u << p;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t idx = hg_index(c.gx + (k & 1), c.gy + ((k >> 1) & 1), c.gz + ((k >> 2) & 1), c.hsize, c.res);
+      const int s = (int)(idx / epb);
+      if (local) packed[p][k] = idx | ((uint32_t)atomicAdd(&hist[s], 1) << 19);
+      else packed[p][k] = (uint32_t)atomicAdd(&ws[y.bin_cursor + sb + s], 1);     // absolute record position
+    }
+  }
+  if (local) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < ns; i += HB_THREADS) {
+      const int n = hist[i];
+      hist[i] = n ? atomicAdd(&ws[y.bin_cursor + sb + i], n) : 0;       // start of this workgroup's run
+    }
+    __syncthreads();
+  }
+  uint32_t* rec = (uint32_t*)((char*)ws + y.rec_off_bytes);
+#pragma unroll
+  for (int p = 0; p < HB_PTS; ++p) {
+    if (!(live & (1u << p))) continue;
+    const uint32_t b = (blockIdx.x * HB_PTS + p) * HB_THREADS + threadIdx.x;
+    const HgCell c = hg_locate(inputs, lv, b);
+    const float wx[2] = {1.f - c.sx, c.sx}, wy[2] = {1.f - c.sy, c.sy}, wz[2] = {1.f - c.sz, c.sz};
+    float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+    if (MODE != 0) {
+      q0 = gg_inputs[(size_t)b * 3 + 0] * c.dx * c.scale;
+      q1 = gg_inputs[(size_t)b * 3 + 1] * c.dy * c.scale;
+      q2 = gg_inputs[(size_t)b * 3 + 2] * c.dz * c.scale;
+    }
+    float g1[C], g2[C];
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) {
+      g1[ch] = grad[((size_t)level * B + b) * C + ch];
+      g2[ch] = (MODE == 2) ? grad2[((size_t)level * B + b) * C + ch] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int bx = k & 1, by = (k >> 1) & 1, bz = (k >> 2) & 1;
+      const float wk = wx[bx] * wy[by] * wz[bz];
+      const float qk = (bx ? 1.f : -1.f) * wy[by] * wz[bz] * q0 + (by ? 1.f : -1.f) * wx[bx] * wz[bz] * q1 +
+                       (bz ? 1.f : -1.f) * wx[bx] * wy[by] * q2;
+      uint32_t idx, pos;
+      if (local) {
+        idx = packed[p][k] & ((1u << 19) - 1);
+        pos = (uint32_t)hist[idx / epb] + (packed[p][k] >> 19);
+      } else {
+        idx = hg_index(c.gx + bx, c.gy + by, c.gz + bz, c.hsize, c.res);
+        pos = packed[p][k];
+      }
+      uint32_t* r = rec + (size_t)pos * (1 + C);
+      r[0] = idx % epb;
+#pragma unroll
+      for (int ch = 0; ch < C; ++ch) {
+        float v;
+        if (MODE == 0) v = wk * g1[ch];
+        else if (MODE == 1) v = qk * g1[ch];
+        else v = wk * g1[ch] + qk * g2[ch];
+        r[1 + ch] = __float_as_uint(v);
+      }
+    }
+  }
+}
+
+template <int C>
+__global__ void __launch_bounds__(HB_THREADS)
+hb_accumulate_k(const int* __restrict__ ws, const HbLayout y, float* __restrict__ grad_grid) {
+  __shared__ float acc[HB_SLICE_FLOATS];
+  const int w = blockIdx.x;
+  if (w >= ws[1]) return;
+  const int4 d = *(const int4*)(ws + y.work + 4 * w);
+  const int r0 = d.x, r1 = d.y;
+  const uint32_t nf = (uint32_t)(d.w & 0x3fffffff);
+  const bool shared_slice = (d.w & 0x40000000) != 0;
+  constexpr uint32_t epb = HB_SLICE_FLOATS / C;
+  for (uint32_t i = threadIdx.x; i < HB_SLICE_FLOATS; i += HB_THREADS) acc[i] = 0.f;
+  __syncthreads();
+  const uint32_t* rec = (const uint32_t*)((const char*)ws + y.rec_off_bytes);
+  // eight records per lane in flight: the loop is a chain of (HBM load -> LDS add) otherwise
+  constexpr int U = 8;
+  for (int i0 = r0 + (int)threadIdx.x; i0 < r1; i0 += U * HB_THREADS) {
+    uint32_t e[U];
+    float v[U][C];
+    // every load is issued (index clamped to the last record): a branch around a load makes the compiler wait for
+    // each one in turn (cdna_hip_programming.md, "Projection GEMM" item 4c)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = min(i0 + u * HB_THREADS, r1 - 1);
+      const uint32_t* r = rec + (size_t)i * (1 + C);
+      e[u] = r[0];
+#pragma unroll
+      for (int ch = 0; ch < C; ++ch) v[u][ch] = __uint_as_float(r[1 + ch]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (i0 + u * HB_THREADS < r1) {
+        // channel planes: the 64 lanes of one ds_add_f32 spread over all 32 banks.  (Measured, B = 104,448: these
+        // LDS float atomics ARE what bounds this kernel -- 0.133 of its 0.155 ms, ~86 cycles per wave-instruction,
+        // the same with interleaved channels; loads 0.02 ms, flush 0.005 ms: profiles/r02_hash_scatter.md)
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) {
+          atomicAdd(&acc[ch * epb + e[u]], v[u][ch]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float* table = grad_grid + (size_t)(uint32_t)d.z;
+  if (!shared_slice) {
+    // this workgroup owns the slice: plain read-modify-write, one entry (C floats) per lane and step.  Level offsets
+    // are arbitrary entry counts (12,167 ...), so a table row is aligned to one entry, not to 16 bytes.
+    typedef float vcf __attribute__((ext_vector_type(C)));
+    vcf* tc = (vcf*)table;
+    const uint32_t ne = nf / C;
+    constexpr int UF = 8;
+    for (uint32_t i0 = threadIdx.x; i0 < ne; i0 += UF * HB_THREADS) {
+      vcf t[UF];
+#pragma unroll
+      for (int u = 0; u < UF; ++u) t[u] = tc[min(i0 + u * HB_THREADS, ne - 1)];      // all loads issued, see above
+#pragma unroll
+      for (int u = 0; u < UF; ++u) {
+        const uint32_t i = i0 + u * HB_THREADS;
+        if (i < ne) {
+          vcf a;
+#pragma unroll
+          for (int ch = 0; ch < C; ++ch) a[ch] = acc[ch * epb + i];
+          tc[i] = t[u] + a;
+        }
+      }
+    }
+  } else {
+    for (uint32_t i = threadIdx.x; i < nf; i += HB_THREADS) {
+      const float v = acc[(i % C) * epb + i / C];
+      if (v != 0.f) unsafeAtomicAdd(table + i, v);  // neighbouring lanes, neighbouring floats: the fast atomic shape
+    }
+  }
+}
+
+template <int C, int MODE>
+static int hb_run(const float* grad, const float* grad2, const float* inputs, const int* offsets,
+                  const float* gg_inputs, float* grad_grid, const uint32_t B, const uint32_t L, const float S,
+                  const uint32_t H, const uint64_t n_entries, void* workspace, const size_t workspace_bytes,
+                  hipStream_t st) {
+  const HbLayout y = hb_layout(B, C, L, n_entries);
+  if (workspace == nullptr || workspace_bytes < y.total_bytes || ((uintptr_t)workspace & 15)) return MSDF_ERR_ARG;
+  if (n_entries * C >= (1ull << 31)) return MSDF_ERR_UNSUPPORTED;
+  int* ws = (int*)workspace;
+  const dim3 grid_pl((B + HB_PTS * HB_THREADS - 1) / (HB_PTS * HB_THREADS), L);
+  hb_setup_k<<<1, HB_THREADS, 0, st>>>(ws, y, offsets, L, C);
+  hb_count_k<C><<<grid_pl, HB_THREADS, 0, st>>>(inputs, offsets, ws, y, B, S, H);
+  hb_scan_k<<<1, 1024, 0, st>>>(ws, y, offsets, L, C);
+  hb_place_k<C, MODE><<<grid_pl, HB_THREADS, 0, st>>>(grad, grad2, inputs, offsets, gg_inputs, ws, y, B, S, H);
+  hb_accumulate_k<C><<<(unsigned)y.work_max, HB_THREADS, 0, st>>>(ws, y, grad_grid);
+  return MSDF_OK;
+}
+
 // grad_inputs[b,d] = sum_{l,c} grad[l,b,c] * dy_dx[b,l,d,c]
 template <int C>
 __global__ void __launch_bounds__(HG_THREADS)
@@ -373,6 +708,76 @@ extern "C" int msdf_hash_encode_backward(const float* grad, const float* inputs,
     }
     if (calc_grad_inputs)
       hg_backward_input_kernel<CC><<<grid.x, HG_THREADS, 0, st>>>(grad, dy_dx, grad_inputs, B, L);
+  });
+  return msdf_check_launch();
+}
+
+extern "C" int64_t msdf_hash_scatter_workspace_bytes(uint32_t B, uint32_t C, uint32_t L, uint64_t n_entries) {
+  return (int64_t)hb_layout(B, C, L, n_entries).total_bytes;
+}
+
+extern "C" int msdf_hash_encode_backward_ws(const float* grad, const float* inputs, const float* embeddings,
+                                            const int* offsets, float* grad_embeddings, uint32_t B, uint32_t D,
+                                            uint32_t C, uint32_t L, float S, uint32_t H, int calc_grad_inputs,
+                                            const float* dy_dx, float* grad_inputs, uint64_t n_entries,
+                                            void* workspace, uint64_t workspace_bytes, void* stream) {
+  (void)embeddings;
+  if (D != 3) return MSDF_ERR_UNSUPPORTED;
+  if (B == 0) return MSDF_OK;
+  hipStream_t st = (hipStream_t)stream;
+  HG_DISPATCH_C(C, {
+    if (grad_embeddings != nullptr) {
+      const int rc = hb_run<CC, 0>(grad, nullptr, inputs, offsets, nullptr, grad_embeddings, B, L, S, H, n_entries,
+                                   workspace, workspace_bytes, st);
+      if (rc != MSDF_OK) return rc;
+    }
+    if (calc_grad_inputs)
+      hg_backward_input_kernel<CC><<<(B + HG_THREADS - 1) / HG_THREADS, HG_THREADS, 0, st>>>(grad, dy_dx, grad_inputs, B, L);
+  });
+  return msdf_check_launch();
+}
+
+extern "C" int msdf_hash_encode_second_backward_ws(const float* grad, const float* inputs, const float* embeddings,
+                                                   const int* offsets, uint32_t B, uint32_t D, uint32_t C,
+                                                   uint32_t L, float S, uint32_t H, int calc_grad_inputs,
+                                                   const float* dy_dx, const float* grad_grad_inputs,
+                                                   float* grad_grad, float* grad2_embeddings, uint64_t n_entries,
+                                                   void* workspace, uint64_t workspace_bytes, void* stream) {
+  (void)embeddings; (void)calc_grad_inputs;
+  if (D != 3) return MSDF_ERR_UNSUPPORTED;
+  if (C == 1) return MSDF_ERR_UNSUPPORTED;
+  if (B == 0) return MSDF_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((B + HG_THREADS - 1) / HG_THREADS, L);
+  HG_DISPATCH_C(C, {
+    if (grad_grad != nullptr)
+      hg_second_backward_grad_kernel<CC><<<grid, HG_THREADS, 0, st>>>(grad_grad_inputs, dy_dx, grad_grad, B, L);
+    if (grad2_embeddings != nullptr) {
+      const int rc = hb_run<CC, 1>(grad, nullptr, inputs, offsets, grad_grad_inputs, grad2_embeddings, B, L, S, H,
+                                   n_entries, workspace, workspace_bytes, st);
+      if (rc != MSDF_OK) return rc;
+    }
+  });
+  return msdf_check_launch();
+}
+
+// both embedding gradients of one training step in ONE scatter:
+//   grad_embeddings += sum_k [ w_k * grad_first[l,b,c] + coef_k(grad_grad_inputs[b]) * grad_second[l,b,c] ]
+// (the sum of what msdf_hash_encode_backward and msdf_hash_encode_second_backward add for the same points)
+extern "C" int msdf_hash_encode_backward_fused(const float* grad_first, const float* grad_second, const float* inputs,
+                                               const int* offsets, float* grad_embeddings, uint32_t B, uint32_t D,
+                                               uint32_t C, uint32_t L, float S, uint32_t H,
+                                               const float* grad_grad_inputs, uint64_t n_entries, void* workspace,
+                                               uint64_t workspace_bytes, void* stream) {
+  if (D != 3 || C == 1) return MSDF_ERR_UNSUPPORTED;
+  if (B == 0) return MSDF_OK;
+  if (grad_embeddings == nullptr || grad_first == nullptr || grad_second == nullptr || grad_grad_inputs == nullptr)
+    return MSDF_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  HG_DISPATCH_C(C, {
+    const int rc = hb_run<CC, 2>(grad_first, grad_second, inputs, offsets, grad_grad_inputs, grad_embeddings, B, L, S,
+                                 H, n_entries, workspace, workspace_bytes, st);
+    if (rc != MSDF_OK) return rc;
   });
   return msdf_check_launch();
 }

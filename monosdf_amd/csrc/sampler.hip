@@ -13,6 +13,12 @@
 //   msdf_sampler_resample  density / transmittance / pdf / inverse CDF, then either merge 128 new
 //                          samples into the sorted set (another round) or emit the final 64
 //   msdf_sampler_finish    final 64 + near + far + 32 extra -> sorted [N, 98], eikonal sample, points
+//
+// The round decisions live on the device: flags[2r] = bits of max beta after round r, flags[2r+1] = 1 when round
+// r asks for another one.  The kernels of round r > 0 return at once when round r-1 did not ask for them, and the
+// finish kernel derives the size of the dense set from the flags.  A host that enqueues more rounds than needed
+// (it may choose not to read the flags back between rounds) therefore gets the same result as one that stops in
+// time; it only has to check afterwards that the last round it enqueued did not ask for one more.
 #include "common.h"
 
 #define SMP_WAVES 4
@@ -64,7 +70,8 @@ __global__ void __launch_bounds__(64 * SMP_WAVES) smp_init_k(const SmpArgs a) {
   float near_c = fmaxf(fmaxf(fminf(ta0, tb0), fminf(ta1, tb1)), fminf(ta2, tb2));
   float far_c = fminf(fminf(fmaxf(ta0, tb0), fmaxf(ta1, tb1)), fmaxf(ta2, tb2));
   if (far_c < near_c) far_c = 1e9f;
-  const float far = fminf(far_c, a.far);
+  // bound <= 0: no cube test, the constant far of UniformSampler(take_sphere_intersection=False) (ray_sampler.py:64-65)
+  const float far = (a.bound > 0.f) ? fminf(far_c, a.far) : a.far;
   const float near = a.near;
   float sumsq = 0.f;
   float* zrow = a.z + (size_t)ray * a.m_max;
@@ -91,7 +98,10 @@ __global__ void __launch_bounds__(64 * SMP_WAVES) smp_init_k(const SmpArgs a) {
     }
   }
   sumsq = smp_sum(sumsq);
-  if (lane == 0) a.beta[ray] = sqrtf(a.lemma * sumsq);
+  if (lane == 0) {
+    a.beta[ray] = sqrtf(a.lemma * sumsq);
+    if (a.far_out != nullptr) a.far_out[ray] = far;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -112,6 +122,11 @@ __device__ __forceinline__ void smp_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// round r runs only if round r-1 asked for it (flags are zero-initialised by the host)
+__device__ __forceinline__ bool smp_round_active(const SmpArgs& a) {
+  return a.round_idx == 0 || a.flags[2 * (a.round_idx - 1) + 1] != 0u;
 }
 
 // load z / sdf of the ray (after scattering the freshly evaluated sdf values), build dists and d*
@@ -145,7 +160,9 @@ __device__ __forceinline__ void smp_load_ray(const SmpArgs& a, const SmpLds& l, 
     const float sg0 = (s0 > 0.f) ? 1.f : (s0 < 0.f) ? -1.f : 0.f;
     const float sg1 = (s1 > 0.f) ? 1.f : (s1 < 0.f) ? -1.f : 0.f;
     l.dist[i] = aa;
-    l.dstar[i] = (sg0 * sg1 == 1.f) ? ds : 0.f;
+    const float dsv = (sg0 * sg1 == 1.f) ? ds : 0.f;
+    l.dstar[i] = dsv;
+    if (scatter && a.dbg_dstar != nullptr) a.dbg_dstar[(size_t)ray * a.m_max + i] = dsv;
   }
   smp_sync();
 }
@@ -181,12 +198,13 @@ __device__ __forceinline__ float smp_error_bound(const SmpLds& l, const int M, c
 __global__ void __launch_bounds__(64 * SMP_WAVES) smp_beta_k(const SmpArgs a) {
   extern __shared__ float smp_lds_mem[];
   const int ray = blockIdx.x * SMP_WAVES + (threadIdx.x >> 6);
-  if (ray >= a.N) return;
+  if (ray >= a.N || !smp_round_active(a)) return;
   const SmpLds l = smp_lds(smp_lds_mem, a.m_max, a.n_eval);
   smp_load_ray(a, l, ray, true);
   const float beta0 = a.beta0[0];
   float beta = a.beta[ray];
   const float e0 = smp_error_bound(l, a.M, beta0);
+  if (a.dbg_err0 != nullptr && lane_id() == 0) a.dbg_err0[ray] = e0;
   if (e0 <= a.eps) beta = beta0;
   float lo = beta0, hi = beta;
   for (int it = 0; it < a.beta_iters; ++it) {
@@ -197,7 +215,7 @@ __global__ void __launch_bounds__(64 * SMP_WAVES) smp_beta_k(const SmpArgs a) {
   }
   if (lane_id() == 0) {
     a.beta[ray] = hi;
-    atomicMax(a.flag, __float_as_uint(hi));
+    atomicMax(a.flags + 2 * a.round_idx, __float_as_uint(hi));
   }
 }
 
@@ -205,15 +223,15 @@ __global__ void __launch_bounds__(64 * SMP_WAVES) smp_beta_k(const SmpArgs a) {
 __global__ void __launch_bounds__(64 * SMP_WAVES) smp_resample_k(const SmpArgs a) {
   extern __shared__ float smp_lds_mem[];
   const int ray = blockIdx.x * SMP_WAVES + (threadIdx.x >> 6);
-  if (ray >= a.N) return;
+  if (ray >= a.N || !smp_round_active(a)) return;
   const int lane = lane_id();
   const int M = a.M;
   const SmpLds l = smp_lds(smp_lds_mem, a.m_max, a.n_eval);
   const float beta0 = a.beta0[0];
-  const float maxbeta = __uint_as_float(a.flag[0]);
+  const float maxbeta = __uint_as_float(a.flags[2 * a.round_idx]);
   const bool unconverged = maxbeta > beta0;
   const bool more = unconverged && (a.round_idx + 1 < a.max_rounds);
-  if (ray == 0 && lane == 0) a.flag[1] = more ? 1u : 0u;
+  if (ray == 0 && lane == 0) a.flags[2 * a.round_idx + 1] = more ? 1u : 0u;
   smp_load_ray(a, l, ray, false);
   const float beta = a.beta[ray];
   const float inv4b2 = 1.0f / (4.0f * beta * beta);
@@ -260,6 +278,8 @@ __global__ void __launch_bounds__(64 * SMP_WAVES) smp_resample_k(const SmpArgs a
   if (lane == 0) l.dstar[0] = 0.f;
   smp_sync();
   const float* cdf = l.dstar;
+  if (a.dbg_cdf != nullptr)
+    for (int i = lane; i < M; i += 64) a.dbg_cdf[(size_t)ray * a.m_max + i] = cdf[i];
 
   // inverse CDF
   const int n_new = more ? a.n_eval : a.n_final;
@@ -321,12 +341,18 @@ __global__ void __launch_bounds__(64 * SMP_WAVES) smp_finish_k(const SmpArgs a) 
   float* v = smp_lds_mem + (size_t)(threadIdx.x >> 6) * 2 * S;
   float* sorted = v + S;
   const float* zrow = a.z + (size_t)ray * a.m_max;
+  // rounds that ran = 1 + the leading rounds that asked for another one; the dense set holds n_eval of them each.
+  // Row (rounds - 1) of the extra_idx table holds the columns drawn for that size (ray_sampler.py:242-247).
+  int rounds = 1;
+  while (rounds < a.max_rounds && a.flags[2 * (rounds - 1) + 1] != 0u) ++rounds;
+  const int64_t* extra = a.extra_idx + (size_t)(rounds - 1) * a.n_extra;
+  if (a.rounds_out != nullptr && ray == 0 && lane == 0) a.rounds_out[0] = rounds;
   for (int j = lane; j < S; j += 64) {
     float x;
     if (j < a.n_final) x = a.final_z[(size_t)ray * a.n_final + j];
     else if (j == a.n_final) x = a.near;
     else if (j == a.n_final + 1) x = a.far;
-    else x = zrow[a.extra_idx[j - a.n_final - 2]];
+    else x = zrow[min((int)extra[j - a.n_final - 2], rounds * a.n_eval - 1)];
     v[j] = x;
   }
   smp_sync();
@@ -365,6 +391,54 @@ __global__ void __launch_bounds__(64 * SMP_WAVES) smp_finish_k(const SmpArgs a) 
 }
 
 // ---------------------------------------------------------------------------
+// ErrorBoundSampler.get_error_bound as an operator of its own (ray_sampler.py:264-272): one wave per ray
+__global__ void __launch_bounds__(64 * SMP_WAVES) smp_error_bound_k(const float* __restrict__ z,
+                                                                     const float* __restrict__ sdf,
+                                                                     const float* __restrict__ dstar,
+                                                                     const float* __restrict__ beta, const int beta_stride,
+                                                                     const int N, const int M, float* __restrict__ out) {
+  extern __shared__ float smp_lds_mem[];
+  const int ray = blockIdx.x * SMP_WAVES + (threadIdx.x >> 6);
+  if (ray >= N) return;
+  const int lane = lane_id();
+  const SmpLds l = smp_lds(smp_lds_mem, M, 0);
+  for (int i = lane; i < M; i += 64) { l.z[i] = z[(size_t)ray * M + i]; l.sdf[i] = sdf[(size_t)ray * M + i]; }
+  smp_sync();
+  for (int i = lane; i + 1 < M; i += 64) {
+    l.dist[i] = l.z[i + 1] - l.z[i];
+    l.dstar[i] = dstar[(size_t)ray * (M - 1) + i];
+  }
+  smp_sync();
+  const float e = smp_error_bound(l, M, beta[(size_t)ray * beta_stride]);
+  if (lane == 0) out[ray] = e;
+}
+
+// LaplaceDensity.density_func and its derivatives (model/density.py:21-26); beta is one value (stride 0) or one per
+// row of `cols` values (the per-ray beta of the sampler, ray_sampler.py:162,168)
+__global__ void __launch_bounds__(256) laplace_density_k(const float* __restrict__ sdf, const float* __restrict__ beta,
+                                                         const int beta_stride, const int64_t n, const int cols,
+                                                         float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    out[i] = smp_density(sdf[i], beta[(i / cols) * beta_stride]);
+}
+// g_sdf = g * d sigma / d s,  g_beta_part[i] = g * d sigma / d beta (summed per beta by the caller)
+__global__ void __launch_bounds__(256) laplace_density_bwd_k(const float* __restrict__ sdf, const float* __restrict__ beta,
+                                                             const int beta_stride, const int64_t n, const int cols,
+                                                             const float* __restrict__ g, float* __restrict__ g_sdf,
+                                                             float* __restrict__ g_beta_elem) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float s = sdf[i], b = beta[(i / cols) * beta_stride], gi = g[i];
+    const float a = fabsf(s);
+    const float ex = expf(-a / b);                       // d expm1(t)/dt = exp(t), t = -|s|/beta
+    const float sg = (s > 0.f) ? 1.f : (s < 0.f) ? -1.f : 0.f;
+    // sigma = (1/b)(1/2 + 1/2 sg expm1(-a/b));  |s|' = sg, sg^2 = 1 away from 0 (torch: sign(0) = 0 -> grad 0)
+    g_sdf[i] = gi * (1.0f / b) * 0.5f * sg * ex * (-sg / b);
+    const float em1 = expm1f(-a / b);
+    g_beta_elem[i] = gi * (-(1.0f / (b * b)) * (0.5f + 0.5f * sg * em1) + (1.0f / b) * 0.5f * sg * ex * (a / (b * b)));
+  }
+}
+
+// ---------------------------------------------------------------------------
 static int smp_check(const msdf_sampler_args_t* a) {
   if (a == nullptr || a->N < 0 || a->n_eval < 2 || a->m_max < a->n_eval) return MSDF_ERR_ARG;
   return MSDF_OK;
@@ -387,16 +461,52 @@ extern "C" int msdf_sampler_init(const msdf_sampler_args_t* a, void* stream) {
   if (smp_check(a)) return MSDF_ERR_ARG;
   return smp_launch(smp_init_k, a, 0, stream);
 }
+static int smp_round_check(const msdf_sampler_args_t* a) {
+  return a->flags == nullptr || a->round_idx < 0 || a->round_idx >= a->max_rounds || a->M > a->m_max || a->M < 2;
+}
 extern "C" int msdf_sampler_beta(const msdf_sampler_args_t* a, void* stream) {
-  if (smp_check(a) || a->M > a->m_max || a->M < 2) return MSDF_ERR_ARG;
+  if (smp_check(a) || smp_round_check(a)) return MSDF_ERR_ARG;
   return smp_launch(smp_beta_k, a, smp_lds_bytes(a), stream);
 }
 extern "C" int msdf_sampler_resample(const msdf_sampler_args_t* a, void* stream) {
-  if (smp_check(a) || a->M > a->m_max || a->M < 2 || a->n_final > a->n_eval) return MSDF_ERR_ARG;
+  if (smp_check(a) || smp_round_check(a) || a->n_final > a->n_eval) return MSDF_ERR_ARG;
   return smp_launch(smp_resample_k, a, smp_lds_bytes(a), stream);
 }
 extern "C" int msdf_sampler_finish(const msdf_sampler_args_t* a, void* stream) {
-  if (smp_check(a) || a->extra_idx == nullptr && a->n_extra > 0) return MSDF_ERR_ARG;
+  if (smp_check(a) || a->flags == nullptr || (a->extra_idx == nullptr && a->n_extra > 0) ||
+      a->m_max < a->n_eval * a->max_rounds)
+    return MSDF_ERR_ARG;
   const size_t lds = (size_t)SMP_WAVES * 2 * (a->n_final + a->n_extra + 2) * sizeof(float);
   return smp_launch(smp_finish_k, a, lds, stream);
+}
+
+extern "C" int msdf_sampler_error_bound(const float* z, const float* sdf, const float* dstar, const float* beta,
+                                        int beta_stride, int N, int M, float* out, void* stream) {
+  if (N < 0 || M < 2 || (beta_stride != 0 && beta_stride != 1)) return MSDF_ERR_ARG;
+  if (N == 0) return MSDF_OK;
+  const size_t lds = (size_t)SMP_WAVES * 5 * (M + 1) * sizeof(float);
+  if (lds > 160 * 1024) return MSDF_ERR_UNSUPPORTED;
+  if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)smp_error_bound_k,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return MSDF_ERR_LAUNCH;
+  smp_error_bound_k<<<(N + SMP_WAVES - 1) / SMP_WAVES, 64 * SMP_WAVES, lds, (hipStream_t)stream>>>(
+      z, sdf, dstar, beta, beta_stride, N, M, out);
+  return msdf_check_launch();
+}
+
+static int dens_grid(int64_t n) { return (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048); }
+extern "C" int msdf_laplace_density(const float* sdf, const float* beta, int beta_stride, int64_t n, int cols,
+                                    float* out, void* stream) {
+  if (n < 0 || cols < 1 || (beta_stride != 0 && beta_stride != 1)) return MSDF_ERR_ARG;
+  if (n == 0) return MSDF_OK;
+  laplace_density_k<<<dens_grid(n), 256, 0, (hipStream_t)stream>>>(sdf, beta, beta_stride, n, cols, out);
+  return msdf_check_launch();
+}
+extern "C" int msdf_laplace_density_backward(const float* sdf, const float* beta, int beta_stride, int64_t n, int cols,
+                                             const float* g, float* g_sdf, float* g_beta_elem, void* stream) {
+  if (n < 0 || cols < 1 || (beta_stride != 0 && beta_stride != 1)) return MSDF_ERR_ARG;
+  if (n == 0) return MSDF_OK;
+  laplace_density_bwd_k<<<dens_grid(n), 256, 0, (hipStream_t)stream>>>(sdf, beta, beta_stride, n, cols, g, g_sdf,
+                                                                     g_beta_elem);
+  return msdf_check_launch();
 }

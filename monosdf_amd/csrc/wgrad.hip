@@ -53,7 +53,7 @@ __device__ __forceinline__ void wg_wait_outstanding(const int stages_behind) {
 // the two variants met in phi nodes and every k step copied 32 accumulator registers behind an `s_nop 15`
 // that waited out the previous MFMA (a third of the matrix pipe's time).
 template <bool NARROW>
-__device__ __forceinline__ void wgrad_body(const msdf_wgrad_item_t& it, const int split, const float* __restrict__ ws,
+__device__ __forceinline__ void wgrad_body(const msdf_wgrad_item_t& it, const int split,
                                            float* __restrict__ part, const int P_pad, float* lds_f) {
   const int n_splits = it.n_splits;
   const int tid = threadIdx.x;
@@ -73,9 +73,9 @@ __device__ __forceinline__ void wgrad_body(const msdf_wgrad_item_t& it, const in
   const int s_end = min(n_stages_total, s_begin + per);
   const int n_st = max(0, s_end - s_begin);
 
-  const float* X = ws + it.x_off;
-  const float* Y = ws + it.y_off;
-  const float* V = (it.v_off >= 0) ? ws + it.v_off : nullptr;
+  const float* X = it.x;
+  const float* Y = it.y;
+  const float* V = it.v;
   const bool do_mm = it.wy > 0;
 
   v16f acc[na][2];
@@ -183,13 +183,13 @@ __device__ __forceinline__ void wgrad_body(const msdf_wgrad_item_t& it, const in
 
 __global__ void __launch_bounds__(WG_THREADS, 2)
 msdf_wgrad_k(const msdf_wgrad_item_t* __restrict__ items, const int* __restrict__ wg_map,
-             const float* __restrict__ ws, float* __restrict__ part, const int P_pad) {
+             float* __restrict__ part, const int P_pad) {
   extern __shared__ float lds_f[];
   const msdf_wgrad_item_t it = items[wg_map[2 * blockIdx.x]];
   const int split = wg_map[2 * blockIdx.x + 1];
   // wide items: 2 x 4 waves of 128 x 64; narrow items (wy <= 64): 8 x 1 waves of 32 x 64
-  if (it.wy <= 64) wgrad_body<true>(it, split, ws, part, P_pad, lds_f);
-  else wgrad_body<false>(it, split, ws, part, P_pad, lds_f);
+  if (it.wy <= 64) wgrad_body<true>(it, split, part, P_pad, lds_f);
+  else wgrad_body<false>(it, split, part, P_pad, lds_f);
 }
 
 
@@ -223,7 +223,7 @@ __device__ __forceinline__ void wb_split8(const float (&v)[8], wv8bf& hi, wv8bf&
 // zero in the image; only the final store is guarded): straight-line MFMAs instead of a scalar branch per tile.
 template <bool NARROW>
 __device__ __forceinline__ void wgrad_b16_body(const msdf_wgrad_item_t& it, const int split,
-                                               const float* __restrict__ ws, float* __restrict__ part,
+                                               float* __restrict__ part,
                                                const int P_pad, wv8bf* lds_img) {
   const int n_splits = it.n_splits;
   const int tid = threadIdx.x;
@@ -241,9 +241,9 @@ __device__ __forceinline__ void wgrad_b16_body(const msdf_wgrad_item_t& it, cons
   const int s_end = min(n_stages_total, s_begin + per);
   const int n_st = max(0, s_end - s_begin);
 
-  const float* X = ws + it.x_off;
-  const float* Y = ws + it.y_off;
-  const float* V = (it.v_off >= 0) ? ws + it.v_off : nullptr;
+  const float* X = it.x;
+  const float* Y = it.y;
+  const float* V = it.v;
   const bool do_mm = it.wy > 0;
   const bool want_vrow = it.vrow_off >= 0;
 
@@ -372,12 +372,12 @@ __device__ __forceinline__ void wgrad_b16_body(const msdf_wgrad_item_t& it, cons
 
 __global__ void __launch_bounds__(WG_THREADS, 2)
 msdf_wgrad_b16_k(const msdf_wgrad_item_t* __restrict__ items, const int* __restrict__ wg_map,
-                 const float* __restrict__ ws, float* __restrict__ part, const int P_pad) {
+                 float* __restrict__ part, const int P_pad) {
   extern __shared__ wv8bf lds_img[];
   const msdf_wgrad_item_t it = items[wg_map[2 * blockIdx.x]];
   const int split = wg_map[2 * blockIdx.x + 1];
-  if (it.wy <= 64) wgrad_b16_body<true>(it, split, ws, part, P_pad, lds_img);
-  else wgrad_b16_body<false>(it, split, ws, part, P_pad, lds_img);
+  if (it.wy <= 64) wgrad_b16_body<true>(it, split, part, P_pad, lds_img);
+  else wgrad_b16_body<false>(it, split, part, P_pad, lds_img);
 }
 
 
@@ -408,23 +408,23 @@ msdf_reduce_k(const msdf_reduce_rule_t* __restrict__ rules, const int* __restric
 }
 
 extern "C" int msdf_wgrad(const msdf_wgrad_item_t* items_dev, const int32_t* wg_map_dev, int n_wgs,
-                          const float* workspace, float* partials, int P_pad, int precision, void* stream) {
+                          float* partials, int P_pad, int precision, void* stream) {
   if (n_wgs < 0 || P_pad < 0 || (P_pad % WB_NP) != 0) return MSDF_ERR_ARG;
   if (n_wgs == 0 || P_pad == 0) return MSDF_OK;
   if (precision == MSDF_PRECISION_BF16X3) {
     if (hipFuncSetAttribute((const void*)msdf_wgrad_b16_k, hipFuncAttributeMaxDynamicSharedMemorySize,
                             WB_LDS_BYTES) != hipSuccess)
       return MSDF_ERR_LAUNCH;
-    msdf_wgrad_b16_k<<<n_wgs, WG_THREADS, WB_LDS_BYTES, (hipStream_t)stream>>>(items_dev, wg_map_dev, workspace,
-                                                                               partials, P_pad);
+    msdf_wgrad_b16_k<<<n_wgs, WG_THREADS, WB_LDS_BYTES, (hipStream_t)stream>>>(items_dev, wg_map_dev, partials,
+                                                                               P_pad);
     return msdf_check_launch();
   }
   if (precision != MSDF_PRECISION_F32) return MSDF_ERR_ARG;
   if (hipFuncSetAttribute((const void*)msdf_wgrad_k, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS_BYTES) !=
       hipSuccess)
     return MSDF_ERR_LAUNCH;
-  msdf_wgrad_k<<<n_wgs, WG_THREADS, WG_LDS_BYTES, (hipStream_t)stream>>>(items_dev, wg_map_dev, workspace,
-                                                                          partials, P_pad);
+  msdf_wgrad_k<<<n_wgs, WG_THREADS, WG_LDS_BYTES, (hipStream_t)stream>>>(items_dev, wg_map_dev, partials,
+                                                                          P_pad);
   return msdf_check_launch();
 }
 

@@ -1,8 +1,10 @@
 """SDF -> density (reference: code/model/density.py:5-30).  ``LaplaceDensity.forward`` is used by
-callers outside the fused path; inside MonoSDFNetwork.forward the density is evaluated by the
-compositor / sampler kernels from ``get_beta()``."""
+callers outside the fused path (its own HIP kernel, forward and backward); inside
+MonoSDFNetwork.forward the density is evaluated by the compositor / sampler kernels from ``get_beta()``."""
 import torch
 import torch.nn as nn
+
+from .. import ops
 
 
 class Density(nn.Module):
@@ -23,7 +25,9 @@ class LaplaceDensity(Density):
     def density_func(self, sdf, beta=None):
         if beta is None:
             beta = self.get_beta()
-        return (1 / beta) * (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() / beta))
+        if not torch.is_tensor(beta):
+            beta = torch.tensor(float(beta), device=sdf.device)
+        return ops.LaplaceDensityFunction.apply(sdf, beta)
 
     def get_beta(self):
         return self.beta.abs() + self.beta_min

@@ -152,12 +152,21 @@ class _SdfBase(_FusedNet):
             save = torch.is_grad_enabled()
         x = x.detach()
         fused, flat_w, flat_b, wpack, bpack = self.packed(x.device)
+        ns = x.shape[0] if split is None else int(split)
+        if self.aux_active and ops.HASH_SCATTER == 'binned' and self.encoding.level_dim > 1:
+            # encoding + MLP + grid part of d sdf/dx as one autograd node: one embedding scatter per backward pass
+            enc = self.encoding
+            fused.grid_offsets = enc.offsets
+            sdf, _, feat, nrm, nrm_b = ops.GridSdfFunction.apply(
+                x, enc.embeddings, flat_w, flat_b, wpack, bpack, fused,
+                (enc.num_levels, enc.level_dim, enc.log2_scale, int(enc.base_resolution)), int(n_clamp), int(n_feat),
+                self.sphere_scale, bool(save), ns, float(self.divide_factor))
+            return (sdf, feat, nrm) if split is None else (sdf, feat, nrm, nrm_b)
         aux, handle = None, None
         if self.aux_active:
             aux, handle = self.encoding.encode_with_jacobian((x / self.divide_factor + 1.0) / 2.0)
             aux = self._pad_aux(aux)
         radius = self.sdf_bounding_sphere if self.clamps else 0.0
-        ns = x.shape[0] if split is None else int(split)
         sdf, _, feat, nrm, nrm_b, r_aux = ops.SdfMlpFunction.apply(
             x, aux, flat_w, flat_b, wpack, bpack, fused, int(n_clamp), int(n_feat), radius, self.sphere_scale,
             bool(save), ns)
@@ -388,8 +397,9 @@ class MonoSDFNetwork(nn.Module):
             # The sampler reads one batch-global flag per round back to the host, and the GPU would drain while the
             # host waits and then issues the big kernels.  So the first attempt runs as many rounds as the previous
             # call needed WITHOUT reading the flags, enqueues everything, and only then looks at them (they have
-            # been on their way since the sampler kernels finished); a wrong guess repeats the pass with the syncs.
-            guess = max(1, self.ray_sampler.last_rounds) if self.speculate_rounds else 0
+            # been on their way since the sampler kernels finished).  Rounds enqueued beyond the ones the flags ask
+            # for return at once on the device, so only a guess that was too SMALL repeats the pass (with the syncs).
+            guess = self.ray_sampler.guess_rounds() if self.speculate_rounds else 0
             for attempt in (guess, 0):
                 # the sampler's last kernel also writes the sample points and (training) the eikonal points
                 z_vals, z_samples_eik, x_all = self.ray_sampler.sample(ray_dirs, cam_loc, self, speculate=attempt)

@@ -141,14 +141,18 @@ class FusedMlp:
         wg_map = ent['wg_map']
         held = list(base_addr.values())
 
+        rules_dev = ent['rules']
+
         def launch(stream=None):
             if stream is not None:
-                for t in held + [part, grad]:
-                    t.record_stream(stream)      # allocated on the main stream, used on this one
+                # allocated on the main stream, used on this one: the work tables too (an evicted items table may
+                # otherwise return to the main stream's pool while the side stream still reads it)
+                for t in held + [part, grad, items_dev, wg_map, rules_dev, self.maps_dev]:
+                    t.record_stream(stream)
             st = _lib.stream_ptr()
-            _lib.call('msdf_wgrad', _lib.ptr(items_dev), _lib.ptr(wg_map), wg_map.numel() // 2, None,
+            _lib.call('msdf_wgrad', _lib.ptr(items_dev), _lib.ptr(wg_map), wg_map.numel() // 2,
                       _lib.ptr(part), P_pad, PRECISIONS.index(self.precision), st)
-            _lib.call('msdf_reduce', _lib.ptr(ent['rules']), len(prog.rules), _lib.ptr(self.maps_dev),
+            _lib.call('msdf_reduce', _lib.ptr(rules_dev), len(prog.rules), _lib.ptr(self.maps_dev),
                       _lib.ptr(part), _lib.ptr(grad), st)
 
         if defer:
@@ -161,56 +165,69 @@ class FusedMlp:
 # ---------------------------------------------------------------------------
 # weight normalisation of a whole network (one launch forward, one backward)
 # ---------------------------------------------------------------------------
+class WeightNormTables:
+    """One immutable set of device tables for msdf_weightnorm_*: pointers of (v, g, b) per layer."""
+
+    def __init__(self, shapes, tensors):
+        """shapes: [(rows, cols, has_g)] per layer; tensors: the parameters in (v, [g], b) order."""
+        dev = tensors[0].device
+        recs, row_layer, w_off, b_off, it = [], [], 0, 0, iter(tensors)
+        for i, (rows, cols, has_g) in enumerate(shapes):
+            r = _lib.WnLayer()
+            v = next(it)
+            g = next(it) if has_g else None
+            b = next(it)
+            r.v, r.g, r.b = v.data_ptr(), (g.data_ptr() if has_g else None), b.data_ptr()
+            r.rows, r.cols = rows, cols
+            r.w_off, r.b_off, r.row_off, r.has_g = w_off, b_off, b_off, int(has_g)
+            recs.append(bytes(r))
+            row_layer += [i] * rows
+            w_off += rows * cols
+            b_off += rows
+        self.layers_dev = torch.from_numpy(np.frombuffer(b''.join(recs), dtype=np.uint8).copy()).to(dev)
+        self.row_layer_dev = torch.tensor(row_layer, dtype=torch.int32, device=dev)
+        self.n_w, self.total_rows = w_off, b_off
+
+
 class WeightNormState:
-    """Device tables for msdf_weightnorm_*: rebuilt only when a parameter's storage moves."""
+    """Cache of WeightNormTables keyed by the parameters' storage addresses (rebuilt when a parameter moves).
+    A table object is never modified once built: a pending backward keeps the one it was given."""
 
     def __init__(self):
-        self.key = None
+        self.key, self.cur = None, None
 
-    def tables(self, layers):
-        dev = layers[0].bias.device
-        key = tuple((l.weight_v.data_ptr() if l.has_weight_norm else l.weight.data_ptr(),
-                     l.weight_g.data_ptr() if l.has_weight_norm else 0, l.bias.data_ptr()) for l in layers)
+    def tables(self, shapes, tensors):
+        key = tuple(t.data_ptr() for t in tensors)
         if key != self.key:
-            recs, row_layer, w_off, b_off = [], [], 0, 0
-            for i, l in enumerate(layers):
-                r = _lib.WnLayer()
-                v = l.weight_v if l.has_weight_norm else l.weight
-                r.v, r.g, r.b = v.data_ptr(), (l.weight_g.data_ptr() if l.has_weight_norm else None), l.bias.data_ptr()
-                r.rows, r.cols = l.out_features, l.in_features
-                r.w_off, r.b_off, r.row_off, r.has_g = w_off, b_off, b_off, int(l.has_weight_norm)
-                recs.append(bytes(r))
-                row_layer += [i] * l.out_features
-                w_off += l.out_features * l.in_features
-                b_off += l.out_features
-            self.layers_dev = torch.from_numpy(np.frombuffer(b''.join(recs), dtype=np.uint8).copy()).to(dev)
-            self.row_layer_dev = torch.tensor(row_layer, dtype=torch.int32, device=dev)
-            self.n_w, self.total_rows = w_off, b_off
+            self.cur = WeightNormTables(shapes, tensors)
             self.key = key
-        return self
+        return self.cur
 
 
 class FusedWeightNormFunction(torch.autograd.Function):
     """(v_0, g_0, b_0, v_1, g_1, b_1, ...) -> (flat effective weights, flat biases)."""
 
     @staticmethod
-    def forward(ctx, state, layers, *params):
-        st = state.tables(layers)
+    def forward(ctx, state, shapes, *params):
+        st = state.tables(shapes, params)
         dev = params[0].device
         flat_w = torch.empty(st.n_w, device=dev, dtype=torch.float32)
         flat_b = torch.empty(st.total_rows, device=dev, dtype=torch.float32)
         norms = torch.empty(st.total_rows, device=dev, dtype=torch.float32)
         _lib.call('msdf_weightnorm_forward', _lib.ptr(st.layers_dev), _lib.ptr(st.row_layer_dev), st.total_rows,
                   _lib.ptr(flat_w), _lib.ptr(flat_b), _lib.ptr(norms), _lib.stream_ptr())
-        ctx.st, ctx.layers = st, layers
-        ctx.save_for_backward(norms)
+        # the backward kernel re-reads v and g: saving them puts them under autograd's version check (an in-place
+        # update between forward and backward raises instead of silently giving the gradient of other weights)
+        ctx.state, ctx.shapes = state, shapes
+        ctx.save_for_backward(norms, *params)
         return flat_w, flat_b
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_w, g_b):
-        st, layers = ctx.st, ctx.layers
-        norms, = ctx.saved_tensors
+        norms, *params = ctx.saved_tensors
+        shapes = ctx.shapes
+        st = ctx.state.tables(shapes, params)       # the saved tensors' addresses (same table unless storage moved)
         dev = norms.device
         join_side_work()            # g_w may have been produced on the side stream
         g_w = g_w.contiguous()
@@ -219,25 +236,26 @@ class FusedWeightNormFunction(torch.autograd.Function):
         _lib.call('msdf_weightnorm_backward', _lib.ptr(st.layers_dev), _lib.ptr(st.row_layer_dev), st.total_rows,
                   _lib.ptr(g_w), _lib.ptr(norms), _lib.ptr(dv), _lib.ptr(dg), _lib.stream_ptr())
         grads, w_off, b_off = [], 0, 0
-        for l in layers:
-            n = l.out_features * l.in_features
-            grads.append(dv[w_off:w_off + n].view(l.out_features, l.in_features))
-            if l.has_weight_norm:
-                grads.append(dg[b_off:b_off + l.out_features].view(l.out_features, 1))
-            grads.append(g_b[b_off:b_off + l.out_features])
+        for rows, cols, has_g in shapes:
+            n = rows * cols
+            grads.append(dv[w_off:w_off + n].view(rows, cols))
+            if has_g:
+                grads.append(dg[b_off:b_off + rows].view(rows, 1))
+            grads.append(g_b[b_off:b_off + rows])
             w_off += n
-            b_off += l.out_features
+            b_off += rows
         return (None, None) + tuple(grads)
 
 
 def fused_weight_norm(state, layers):
-    params = []
+    params, shapes = [], []
     for l in layers:
         params.append(l.weight_v if l.has_weight_norm else l.weight)
         if l.has_weight_norm:
             params.append(l.weight_g)
         params.append(l.bias)
-    return FusedWeightNormFunction.apply(state, layers, *params)
+        shapes.append((l.out_features, l.in_features, bool(l.has_weight_norm)))
+    return FusedWeightNormFunction.apply(state, tuple(shapes), *params)
 
 
 # ---------------------------------------------------------------------------
@@ -344,6 +362,102 @@ class SdfMlpFunction(torch.autograd.Function):
         else:
             grad = torch.zeros(mp.n_w + mp.n_b, device=dev)
         return (None, g_aux, grad[:mp.n_w], grad[mp.n_w:], None, None, None, None, None, None, None, None, None)
+
+
+class _InnerCtx:
+    """Stands in for autograd's ctx when one Function runs another Function's forward / backward inside its own."""
+
+    def __init__(self):
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+    def set_materialize_grads(self, flag):
+        pass
+
+
+class GridSdfFunction(torch.autograd.Function):
+    """Hash-grid encoding + SDF network + d sdf / d x as ONE autograd node (ImplicitNetworkGrid.get_outputs /
+    gradient_sdf, reference network.py:247-309 with hashgrid.py:14-101).
+
+    As three nodes (encode -> MLP -> grid part of d sdf/dx) the backward pass scatters into the embedding table
+    twice: the second-order term when the gradient of d sdf/dx arrives, the first-order term after the MLP's
+    backward kernel.  Both visit the same corners of the same points, so here they are ONE binned scatter
+    (msdf_hash_encode_backward_fused) at the end of the node's backward."""
+
+    @staticmethod
+    def forward(ctx, x, embeddings, flat_w, flat_b, wpack, bpack, mlp, enc, n_clamp, n_feat, sphere_scale, save,
+                n_split, divide_factor):
+        ctx.set_materialize_grads(False)
+        x = _need_cuda(x.detach(), 'points')
+        emb = _need_cuda(embeddings.detach(), 'embeddings')
+        B, D = x.shape
+        L, Cdim, S, H = enc
+        offsets = mlp.grid_offsets
+        x01 = ((x / divide_factor + 1.0) / 2.0).contiguous()
+        outputs = torch.empty(L, B, Cdim, device=x.device, dtype=torch.float32)
+        dy_dx = torch.empty(B, L * D * Cdim, device=x.device, dtype=torch.float32)
+        st = _lib.stream_ptr()
+        _lib.call('msdf_hash_encode_forward', _lib.ptr(x01), _lib.ptr(emb), _lib.ptr(offsets), _lib.ptr(outputs), B, D,
+                  Cdim, L, S, H, 1, _lib.ptr(dy_dx), st)
+        A = 16 * mlp.plan.aux_tiles
+        aux = outputs.permute(1, 0, 2).reshape(B, L * Cdim)
+        if A != L * Cdim:
+            aux = torch.nn.functional.pad(aux, (0, A - L * Cdim))
+        inner = _InnerCtx()
+        # the grid class never clamps (network.py:290-309): clamp radius 0
+        sdf_a, sdf_b, feat, nrm_a, nrm_b, r_aux = SdfMlpFunction.forward(
+            inner, x, aux.contiguous(), flat_w, flat_b, wpack, bpack, mlp, n_clamp, n_feat, 0.0, sphere_scale, save,
+            n_split)
+        # d sdf / d x through the grid: sum_{l,c} (d sdf / d feature) * d feature / d x01, chain rule to x
+        r_lbc = r_aux[:, :L * Cdim].reshape(B, L, Cdim).permute(1, 0, 2).contiguous()
+        through = torch.empty(B, D, device=x.device, dtype=torch.float32)
+        _lib.call('msdf_hash_encode_backward', _lib.ptr(r_lbc), _lib.ptr(x01), _lib.ptr(emb), _lib.ptr(offsets), None,
+                  B, D, Cdim, L, S, H, 1, _lib.ptr(dy_dx), _lib.ptr(through), st)
+        k = 0.5 / divide_factor
+        ns = inner.n_split
+        through = through * k
+        nrm_a = nrm_a + through[:ns]
+        nrm_b = nrm_b + through[ns:]
+        ctx.inner, ctx.enc, ctx.k, ctx.n_entries = inner, enc, k, emb.shape[0]
+        ctx.offsets = offsets
+        ctx.save_for_backward(x01, dy_dx, r_lbc)
+        return sdf_a, sdf_b, feat, nrm_a, nrm_b
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_sdf, g_sdf_b, g_feat, g_nrm, g_nrm_b):
+        x01, dy_dx, r_lbc = ctx.saved_tensors
+        inner, (L, Cdim, S, H), k = ctx.inner, ctx.enc, ctx.k
+        B, D = x01.shape
+        dev = x01.device
+        ns = inner.n_split
+        st = _lib.stream_ptr()
+        # gradient arriving at the grid part of d sdf/dx (the reference's grad_grad_inputs, hashgrid.py:71-84)
+        gg = torch.zeros(B, D, device=dev, dtype=torch.float32)
+        if g_nrm is not None:
+            gg[:ns] = g_nrm
+        if g_nrm_b is not None:
+            gg[ns:] = g_nrm_b
+        gg.mul_(k)
+        # ... its term for d sdf / d feature: grad_grad[l,b,c] = sum_d gg[b,d] dy_dx[b,l,d,c]
+        grad_grad = torch.empty(L, B, Cdim, device=dev, dtype=torch.float32)
+        _lib.call('msdf_hash_encode_second_backward_ws', _lib.ptr(r_lbc), _lib.ptr(x01), None, _lib.ptr(ctx.offsets), B, D,
+                  Cdim, L, S, H, 1, _lib.ptr(dy_dx), _lib.ptr(gg), _lib.ptr(grad_grad), None, ctx.n_entries, None, 0, st)
+        A = 16 * inner.mlp.plan.aux_tiles
+        g_raux = grad_grad.permute(1, 0, 2).reshape(B, L * Cdim)
+        if A != L * Cdim:
+            g_raux = torch.nn.functional.pad(g_raux, (0, A - L * Cdim))
+        res = SdfMlpFunction.backward(inner, g_sdf, g_sdf_b, g_feat, g_nrm, g_nrm_b, g_raux.contiguous())
+        g_aux, g_w, g_b = res[1], res[2], res[3]
+        g1 = g_aux[:, :L * Cdim].reshape(B, L, Cdim).permute(1, 0, 2).contiguous()
+        g_emb = torch.zeros(ctx.n_entries, Cdim, device=dev, dtype=torch.float32)
+        nbytes = _lib.load().msdf_hash_scatter_workspace_bytes(B, Cdim, L, ctx.n_entries)
+        ws = torch.empty(int(nbytes), device=dev, dtype=torch.uint8)
+        _lib.call('msdf_hash_encode_backward_fused', _lib.ptr(g1), _lib.ptr(r_lbc), _lib.ptr(x01), _lib.ptr(ctx.offsets),
+                  _lib.ptr(g_emb), B, D, Cdim, L, S, H, _lib.ptr(gg), ctx.n_entries, _lib.ptr(ws), int(nbytes), st)
+        return (None, g_emb, g_w, g_b) + (None,) * 10
 
 
 # ---------------------------------------------------------------------------
@@ -501,8 +615,53 @@ class CompositeFunction(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------
+# Laplace density as an operator of its own (the fused path evaluates it inside the compositor / sampler)
+# ---------------------------------------------------------------------------
+class LaplaceDensityFunction(torch.autograd.Function):
+    """(sdf [..., cols], beta [1] or one per row) -> sigma (reference: model/density.py:21-26)."""
+
+    @staticmethod
+    def forward(ctx, sdf, beta):
+        s = _need_cuda(sdf.detach(), 'sdf')
+        b = _need_cuda(beta.detach().to(s.device), 'beta').reshape(-1)
+        cols = s.shape[-1] if s.dim() > 0 else 1
+        rows = s.numel() // max(cols, 1)
+        if b.numel() not in (1, rows):
+            raise RuntimeError('monosdf_amd: beta must hold one value or one per row of sdf')
+        stride = int(b.numel() == rows and rows > 1)
+        out = torch.empty_like(s)
+        _lib.call('msdf_laplace_density', _lib.ptr(s), _lib.ptr(b), stride, s.numel(), max(cols, 1), _lib.ptr(out),
+                  _lib.stream_ptr())
+        ctx.save_for_backward(s, b)
+        ctx.meta = (stride, cols, beta.shape)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        s, b = ctx.saved_tensors
+        stride, cols, beta_shape = ctx.meta
+        g = g.contiguous()
+        g_sdf, g_be = torch.empty_like(s), torch.empty_like(s)
+        _lib.call('msdf_laplace_density_backward', _lib.ptr(s), _lib.ptr(b), stride, s.numel(), max(cols, 1),
+                  _lib.ptr(g), _lib.ptr(g_sdf), _lib.ptr(g_be), _lib.stream_ptr())
+        g_beta = (g_be.reshape(-1, max(cols, 1)).sum(1) if stride else g_be.sum()).reshape(beta_shape)
+        return g_sdf, g_beta
+
+
+# ---------------------------------------------------------------------------
 # hash grid (mirrors the reference's two autograd Functions, hashencoder/hashgrid.py:14-101)
 # ---------------------------------------------------------------------------
+# 'binned' (default): the embedding gradients are summed per table slice in LDS (msdf_hash_encode_*_ws, one record per
+# corner through a caller-owned workspace); 'atomic': one float atomic per corner like the reference's kernels
+HASH_SCATTER = _os.environ.get('MSDF_HASH_SCATTER', 'binned')
+
+
+def _hash_workspace(B, Cdim, L, embeddings):
+    n = _lib.load().msdf_hash_scatter_workspace_bytes(B, Cdim, L, embeddings.shape[0])
+    return torch.empty(int(n), device=embeddings.device, dtype=torch.uint8), int(n)
+
+
 class HashEncodeFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, inputs, embeddings, offsets, S, H, calc_grad_inputs):
@@ -542,9 +701,15 @@ class HashEncodeBackwardFunction(torch.autograd.Function):
         # the reference always scatters into grad_embeddings, even when autograd discards it
         # (SURVEY 8a11); want_emb=False skips that wasted pass, the result the caller sees is identical
         g_emb = torch.zeros_like(embeddings) if want_emb else None
-        _lib.call('msdf_hash_encode_backward', _lib.ptr(grad), _lib.ptr(inputs), _lib.ptr(embeddings),
-                  _lib.ptr(offsets), _lib.ptr(g_emb), B, D, Cdim, L, S, H, int(calc_grad_inputs),
-                  _lib.ptr(dy_dx), _lib.ptr(g_in), _lib.stream_ptr())
+        if want_emb and HASH_SCATTER == 'binned':
+            ws, nbytes = _hash_workspace(B, Cdim, L, embeddings)
+            _lib.call('msdf_hash_encode_backward_ws', _lib.ptr(grad), _lib.ptr(inputs), _lib.ptr(embeddings),
+                      _lib.ptr(offsets), _lib.ptr(g_emb), B, D, Cdim, L, S, H, int(calc_grad_inputs),
+                      _lib.ptr(dy_dx), _lib.ptr(g_in), embeddings.shape[0], _lib.ptr(ws), nbytes, _lib.stream_ptr())
+        else:
+            _lib.call('msdf_hash_encode_backward', _lib.ptr(grad), _lib.ptr(inputs), _lib.ptr(embeddings),
+                      _lib.ptr(offsets), _lib.ptr(g_emb), B, D, Cdim, L, S, H, int(calc_grad_inputs),
+                      _lib.ptr(dy_dx), _lib.ptr(g_in), _lib.stream_ptr())
         if g_emb is None:
             g_emb = embeddings.new_zeros(1)
         ctx.save_for_backward(grad, inputs, embeddings, offsets, dy_dx)
@@ -560,9 +725,16 @@ class HashEncodeBackwardFunction(torch.autograd.Function):
         gg_in = _need_cuda(gg_in, 'grad_grad_inputs')
         grad_grad = torch.zeros_like(grad)
         grad2_emb = torch.zeros_like(embeddings)
-        _lib.call('msdf_hash_encode_second_backward', _lib.ptr(grad), _lib.ptr(inputs), _lib.ptr(embeddings),
-                  _lib.ptr(offsets), B, D, Cdim, L, S, H, int(ctx.calc_grad_inputs), _lib.ptr(dy_dx),
-                  _lib.ptr(gg_in), _lib.ptr(grad_grad), _lib.ptr(grad2_emb), _lib.stream_ptr())
+        if HASH_SCATTER == 'binned' and Cdim > 1:
+            ws, nbytes = _hash_workspace(B, Cdim, L, embeddings)
+            _lib.call('msdf_hash_encode_second_backward_ws', _lib.ptr(grad), _lib.ptr(inputs), _lib.ptr(embeddings),
+                      _lib.ptr(offsets), B, D, Cdim, L, S, H, int(ctx.calc_grad_inputs), _lib.ptr(dy_dx),
+                      _lib.ptr(gg_in), _lib.ptr(grad_grad), _lib.ptr(grad2_emb), embeddings.shape[0], _lib.ptr(ws),
+                      nbytes, _lib.stream_ptr())
+        else:
+            _lib.call('msdf_hash_encode_second_backward', _lib.ptr(grad), _lib.ptr(inputs), _lib.ptr(embeddings),
+                      _lib.ptr(offsets), B, D, Cdim, L, S, H, int(ctx.calc_grad_inputs), _lib.ptr(dy_dx),
+                      _lib.ptr(gg_in), _lib.ptr(grad_grad), _lib.ptr(grad2_emb), _lib.stream_ptr())
         return grad_grad, None, grad2_emb, None, None, None, None, None
 
 

@@ -26,19 +26,58 @@ def shard_slice(n_items, rank_=None, world_=None):
     return start, start + base + (1 if r < rem else 0)
 
 
+class GradientAverager:
+    """Mean of .grad over all ranks with ONE all-reduce of a persistent flat buffer per step.
+
+    The layout is fixed at construction from the parameters that require gradients, so every rank reduces the
+    same message even when a parameter has no gradient on some rank (its slot is zero there).  Gradients are
+    gathered into the buffer with one multi-tensor copy; afterwards each ``p.grad`` IS a view of the buffer (no
+    copy back, no per-step allocation).  2.7 MB for the 8x256 network, 50 MB with the hash grid: on xGMI that is
+    tens of microseconds against a 9 ms step, so it is not overlapped with the backward pass."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError('no parameter requires a gradient')
+        dev, dt = self.params[0].device, self.params[0].dtype
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), device=dev, dtype=dt)
+        self.views, off = [], 0
+        for p in self.params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+
+    def average(self, group=None):
+        w = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        src, dst = [], []
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                src.append(p.grad)
+                dst.append(v)
+        if src:
+            torch._foreach_copy_(dst, src)
+        if w > 1:
+            dist.all_reduce(self.flat, group=group)
+            self.flat.div_(w)
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+        return self.flat
+
+
+_AVERAGERS = {}
+
+
 def average_gradients(params):
-    """In-place mean of .grad over all ranks with one flat all-reduce."""
-    w = world()
-    if w == 1:
+    """In-place mean of .grad over all ranks (a GradientAverager cached per parameter list)."""
+    params = list(params)
+    if world() == 1:
         return
-    grads = [p.grad for p in params if p.grad is not None]
-    flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat)
-    flat /= w
-    off = 0
-    for g in grads:
-        g.copy_(flat[off:off + g.numel()].view_as(g))
-        off += g.numel()
+    key = tuple(id(p) for p in params)
+    if key not in _AVERAGERS:
+        _AVERAGERS.clear()
+        _AVERAGERS[key] = GradientAverager(params)
+    _AVERAGERS[key].average()
 
 
 def all_gather_rows(t):

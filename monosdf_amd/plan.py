@@ -329,10 +329,10 @@ class WgradProgram:
         for it in self.items:
             w = _lib.WgradItem()
             ax = base_addr[it['x'][0]]
-            w.x_off = ax // 4 + it['x'][1]
+            w.x = ax + 4 * it['x'][1]
             ay = base_addr[it['y'][0]] if it['y'] is not None else ax
-            w.y_off = ay // 4 + (it['y'][1] if it['y'] is not None else 0)
-            w.v_off = (base_addr[it['v'][0]] // 4 + it['v'][1]) if it['v'] is not None else -1
+            w.y = ay + 4 * (it['y'][1] if it['y'] is not None else 0)
+            w.v = (base_addr[it['v'][0]] + 4 * it['v'][1]) if it['v'] is not None else None
             w.part_off, w.colsum_off, w.vrow_off = it['part_off'], it['colsum_off'], it['vrow_off']
             w.x_ld, w.y_ld, w.wx, w.wy = it['x_ld'], it['y_ld'], it['wx'], it['wy']
             w.n_splits = it['n_splits']

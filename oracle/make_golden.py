@@ -62,7 +62,20 @@ CASES = {
     'mlp_w64_eval': dict(kind='mlp', width=64, n_rays=24, jitter=0.3, training=False),
     'mlp_w64_eval_sharp': dict(kind='mlp', width=64, n_rays=24, jitter=0.0, beta=0.01, training=False),
     'mlp_w64_eval_vsharp': dict(kind='mlp', width=64, n_rays=16, jitter=0.05, beta=0.002, training=False),
-    'mlp_w64_eval_maxit': dict(kind='mlp', width=64, n_rays=8, jitter=0.02, beta=0.0003, training=False),
+    'mlp_w64_eval_k3': dict(kind='mlp', width=64, n_rays=8, jitter=0.02, beta=0.0003, training=False),
+    # sdf_scale < 1: |sdf| under-estimates the distance to the surface, the sampler needs 4 / 5 rounds or leaves
+    # the loop at max_total_iters without converging (ray_sampler.py:125,179-207); trace = per-round intermediates
+    'mlp_w64_eval_k4': dict(kind='mlp', width=64, n_rays=6, jitter=0.05, beta=0.0005, sdf_scale=0.25,
+                            training=False, trace=True),
+    'mlp_w64_eval_k5': dict(kind='mlp', width=64, n_rays=6, jitter=0.3, beta=0.002, sdf_scale=0.25,
+                            training=False, trace=True),
+    'mlp_w64_eval_k5nc': dict(kind='mlp', width=64, n_rays=6, jitter=0.3, beta=0.001, sdf_scale=0.25,
+                              training=False, trace=True),
+    'mlp_w64_train_k4': dict(kind='mlp', width=64, n_rays=6, jitter=0.05, beta=0.0005, sdf_scale=0.25,
+                             training=True, grads=True, trace=True),
+    'mlp_w64_train_k5nc': dict(kind='mlp', width=64, n_rays=6, jitter=0.3, beta=0.001, sdf_scale=0.25,
+                               training=True, grads=True),
+    'mlp_w64_eval_k2_trace': dict(kind='mlp', width=64, n_rays=6, jitter=0.0, beta=0.01, training=False, trace=True),
     'mlp_w64_train': dict(kind='mlp', width=64, n_rays=24, jitter=0.3, training=True, grads=True),
     'mlp_w64_train_sharp': dict(kind='mlp', width=64, n_rays=16, jitter=0.1, beta=0.01, training=True, grads=True),
     'mlp_w64_image_eval': dict(kind='mlp', width=64, n_rays=20, jitter=0.3, training=False, image_mode=True),
@@ -89,7 +102,8 @@ def digest(t):
 
 def run_case(name, spec):
     conf = conf_from_spec(spec)
-    state = synth.make_state(conf, seed=spec.get('weight_seed', 0), jitter=spec['jitter'])
+    state = synth.make_state(conf, seed=spec.get('weight_seed', 0), jitter=spec['jitter'],
+                             sdf_scale=spec.get('sdf_scale', 1.0))
     inputs, indices = make_inputs(spec)
     pixel = not spec.get('image_mode', False)
     model = ref_loader.build_model(conf, state, training=spec['training'])
@@ -101,11 +115,19 @@ def run_case(name, spec):
         return orig(x)
     model.implicit_network.get_sdf_vals = counted
     torch.manual_seed(spec.get('torch_seed', 1234))
-    with ref_loader.record_rng() as log:
+    with ref_loader.record_rng() as log, ref_loader.record_sampler(model) as trace:
         out = model({k: v.clone() for k, v in inputs.items()}, indices, if_pixel_input=pixel)
     noise = ref_loader.noise_from_log(log)
     rec = {'spec': np.frombuffer(repr(sorted(spec.items())).encode(), dtype=np.uint8),
            'rounds': np.asarray(rounds[0]), 'indices': indices.numpy()}
+    assert len(trace) == rounds[0]
+    # did the loop end because every ray's beta reached beta0, or at max_total_iters (ray_sampler.py:125,179)?
+    beta0 = float(model.density.get_beta())
+    rec['converged'] = np.asarray(bool(trace[-1]['beta'].max() <= beta0))
+    if spec.get('trace'):
+        for r, t in enumerate(trace):
+            for k, v in t.items():
+                rec['smp.r%d.%s' % (r, k)] = v.numpy()
     for k, v in inputs.items():
         rec['in.' + k] = v.numpy()
     for k, v in noise.items():
@@ -187,6 +209,44 @@ def run_stages():
     return rec
 
 
+PLUMBING = dict(kind='mlp', width=256, n_rays=512, n_samples=64, jitter=0.3, ray_seed=1, weight_seed=0)
+
+
+def run_plumbing():
+    """BASELINE.json configs[0] ("512 rays x 64 uniform samples, fp32 PyTorch CPU, plumbing"): the reference's own
+    UniformSampler + ImplicitNetwork.get_outputs + RenderingNetwork + volume_rendering + composites, composed the
+    way MonoSDFNetwork.forward composes them (network.py:532-562,603-611), at the 8x256 model of configs[1]."""
+    ref_loader.load()
+    import model.ray_sampler as rs          # reference module
+    spec = PLUMBING
+    conf = conf_from_spec(spec)
+    state = synth.make_state(conf, seed=spec['weight_seed'], jitter=spec['jitter'])
+    model = ref_loader.build_model(conf, state, training=False)
+    rays = synth.make_rays(spec['n_rays'], seed=spec['ray_seed'], random_pose=True)
+    dirs, cam = rays['ray_dirs'], rays['ray_cam_loc']
+    us = rs.UniformSampler(conf['scene_bounding_sphere'], 0.0, spec['n_samples'], take_sphere_intersection=True)
+    z, near, far = us.get_z_vals(dirs, cam, model)
+    n, s = z.shape
+    pts = (cam.unsqueeze(1) + z.unsqueeze(2) * dirs.unsqueeze(1)).reshape(-1, 3)
+    dirs_flat = dirs.unsqueeze(1).repeat(1, s, 1).reshape(-1, 3)
+    sdf, feat, grad = model.implicit_network.get_outputs(pts)
+    rgb = model.rendering_network(pts, grad, dirs_flat, feat, torch.arange(n))['rgb'].reshape(-1, s, 3)
+    w = model.volume_rendering(z, sdf)
+    rgb_values = torch.sum(w.unsqueeze(-1) * rgb, 1)
+    depth = torch.sum(w * z, 1, keepdims=True) / (w.sum(dim=1, keepdims=True) + 1e-8)
+    depth = rays['ray_dirs_tmp'][:, 2:] * depth
+    normals = grad / (grad.norm(2, -1, keepdim=True) + 1e-6)
+    nmap = torch.sum(w.unsqueeze(-1) * normals.reshape(-1, s, 3), 1)
+    rot = rays['ray_pose'][:, :3, :3].transpose(1, 2)
+    nmap = (rot @ nmap.unsqueeze(-1)).squeeze(-1)
+    k = 8                                     # per-sample tensors: every 8th ray
+    d = lambda t: t.detach().numpy()
+    return {'spec': np.frombuffer(repr(sorted(spec.items())).encode(), dtype=np.uint8),
+            'out.z_vals': d(z), 'out.far': d(far), 'out.rgb_values': d(rgb_values), 'out.depth_values': d(depth),
+            'out.normal_map': d(nmap), 'sub.sdf': d(sdf.reshape(n, s)[::k]), 'sub.weights': d(w[::k]),
+            'sub.rgb': d(rgb[::k])}
+
+
 def main(argv):
     os.makedirs(OUT_DIR, exist_ok=True)
     only = set(argv[1:])
@@ -196,7 +256,12 @@ def main(argv):
         rec = run_case(name, spec)
         path = os.path.join(OUT_DIR, name + '.npz')
         np.savez_compressed(path, **rec)
-        print('%-24s rounds=%d  %6.1f KB' % (name, int(rec['rounds']), os.path.getsize(path) / 1024))
+        print('%-24s rounds=%d converged=%d  %6.1f KB' % (name, int(rec['rounds']), int(rec['converged']),
+                                                         os.path.getsize(path) / 1024))
+    if not only or 'plumbing' in only:
+        path = os.path.join(OUT_DIR, 'plumbing_uniform64.npz')
+        np.savez_compressed(path, **run_plumbing())
+        print('%-24s %6.1f KB' % ('plumbing_uniform64', os.path.getsize(path) / 1024))
     if not only or 'stages' in only:
         path = os.path.join(OUT_DIR, 'stages.npz')
         np.savez_compressed(path, **run_stages())

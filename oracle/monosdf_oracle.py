@@ -253,13 +253,16 @@ def _inverse_cdf(cdf, bins, u):
 
 
 def error_bound_sampler(state, conf, ray_dirs, cam_loc, training=False, noise=None,
-                        sdf_fn=None, trace=None):
+                        sdf_fn=None, trace=None, max_reduce=None):
     """ErrorBoundSampler.get_z_vals (ray_sampler.py:110-262), inverse_sphere_bg=False.
 
     noise (training only): 'jitter' [N,128], 'final_u' [N,64], 'extra_idx' [32] (int64),
     'eik_idx' [N] (int64).  In eval mode 'eik_idx' defaults to zeros (unused by outputs).
     ``sdf_fn(points)->[P,1]`` overrides the network (used to test the sampler alone).
-    ``trace`` (dict) receives the number of rounds and the final beta.
+    ``max_reduce(t)->t`` (multi-rank tests): applied to the batch's max beta before the convergence test, e.g. an
+    all-reduce(MAX), so that a shard runs the rounds the whole batch would.
+    ``trace`` (dict) receives the number of rounds, the final beta and, under 'per_round', each round's
+    sorted z, merged sdf, d*, beta after the bisection, cdf, u and new samples.
     """
     sc = conf['ray_sampler']
     noise = noise or {}
@@ -304,7 +307,8 @@ def error_bound_sampler(state, conf, ray_dirs, cam_loc, training=False, noise=No
         dens = laplace_density(sdf, beta.unsqueeze(-1))
         weights, trans, dists_full = transmittance_weights(z_vals, dens)
         rounds += 1
-        unconverged = bool(beta.max() > beta0)
+        bmax = beta.max() if max_reduce is None else max_reduce(beta.max())
+        unconverged = bool(bmax > beta0)
         more = unconverged and rounds < sc['max_total_iters']
         if more:
             # sample proportionally to the current error bound (ray_sampler.py:181-194)
@@ -324,6 +328,9 @@ def error_bound_sampler(state, conf, ray_dirs, cam_loc, training=False, noise=No
         else:
             u = noise['final_u'].to(dt)
         samples = _inverse_cdf(cdf, z_vals, u)
+        if trace is not None:
+            trace.setdefault('per_round', []).append(
+                {'z': z_vals, 'sdf': sdf, 'dstar': d_star, 'beta': beta, 'cdf': cdf, 'u': u, 'samples': samples})
         if more:
             z_vals, order = torch.sort(torch.cat([z_vals, samples], -1), -1)
 
@@ -431,6 +438,13 @@ def render(state, conf, inputs, indices=None, if_pixel_input=False, training=Fal
         normal_map = (rot @ normal_map.permute(1, 0)).permute(1, 0)
     out['normal_map'] = normal_map
     return out
+
+
+def render_uniform(state, conf, inputs, indices, n_samples):
+    """BASELINE.json configs[0]: the same path with UniformSampler(N_samples=n_samples, take_sphere_intersection=True)
+    in place of the error-bounded sampler (ray_sampler.py:16-83), eval mode, pixel-mode inputs."""
+    z, _, _ = uniform_z(conf, inputs['ray_dirs'], inputs['ray_cam_loc'], n_samples)
+    return render(state, conf, inputs, indices, True, False, None, z_override=(z, None))
 
 
 def probe_loss(out):

@@ -96,6 +96,39 @@ def load():
     return net
 
 
+def load_plots():
+    """The reference's ``utils.plots`` module with the meshing / imaging packages stubbed; returns (module,
+    captured) where ``captured`` collects every volume handed to ``measure.marching_cubes`` (utils/plots.py:199-205)
+    -- that array is what the SDF-volume evaluator has to reproduce."""
+    load()
+    import numpy as np
+    captured = []
+
+    def marching_cubes(volume=None, level=0, spacing=(1., 1., 1.), **kw):
+        captured.append({'volume': np.array(volume, copy=True), 'spacing': tuple(float(v) for v in spacing)})
+        tri = np.eye(3)               # one dummy triangle: the caller prints verts.min() / max()
+        return tri, np.array([[0, 1, 2]]), tri, np.zeros((3,))
+
+    class _Mesh:
+        def __init__(self, *a, **k):
+            pass
+
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    measure = stub('skimage.measure', marching_cubes=marching_cubes)
+    sys.modules['skimage'].measure = measure
+    tv = stub('torchvision', utils=types.SimpleNamespace(make_grid=None))
+    tv.transforms = stub('torchvision.transforms', ToPILImage=lambda *a, **k: None)
+    stub('trimesh', Trimesh=_Mesh, util=types.SimpleNamespace(concatenate=lambda meshes: meshes))
+    stub('termcolor', colored=lambda s, *a, **k: s)
+    import utils.plots as plots        # noqa: E402  (reference module)
+    return plots, captured
+
+
 def build_model(conf, state=None, training=False, if_hdr=False):
     """Instantiate the reference MonoSDFNetwork on CPU and load ``state`` into it."""
     net = load()
@@ -130,6 +163,108 @@ def record_rng():
         yield log
     finally:
         torch.rand, torch.randperm, torch.randint, torch.rand_like, torch.Tensor.uniform_ = saved
+
+
+@contextlib.contextmanager
+def inject_rng(noise, n_rays, conf):
+    """The opposite of record_rng: the six random draws of one training forward of the reference come from
+    ``noise`` (oracle/synth.make_noise_table) instead of torch's generators, matched by call site shape
+    (SURVEY 8(a) RNG note: ray_sampler.py:79,213,244,254; network.py:587,593)."""
+    sc = conf['ray_sampler']
+    saved = (torch.rand, torch.randperm, torch.randint, torch.rand_like, torch.Tensor.uniform_)
+
+    def rand(*shape, **kw):
+        shape = tuple(shape[0]) if len(shape) == 1 and not isinstance(shape[0], int) else tuple(shape)
+        if shape == (n_rays, sc['N_samples_eval']):
+            return noise['jitter'].clone()
+        if shape == (n_rays, sc['N_samples']):
+            return noise['final_u'].clone()
+        raise AssertionError('unexpected torch.rand%r' % (shape,))
+
+    def randperm(m, **kw):
+        row = noise['extra_idx'][m // sc['N_samples_eval'] - 1]
+        rest = torch.tensor([i for i in range(m) if i not in set(row.tolist())], dtype=torch.int64)
+        return torch.cat([row, rest])
+
+    def randint(high, size, **kw):
+        assert tuple(size) == (n_rays,) and high == sc['N_samples'] + sc['N_samples_extra'] + 2
+        return noise['eik_idx'].clone()
+
+    def rand_like(t, **kw):
+        assert tuple(t.shape) == (2 * n_rays, 3)
+        return noise['nei_rand'].clone()
+
+    def uniform_(self, a=0.0, b=1.0, **kw):
+        assert tuple(self.shape) == (n_rays, 3)
+        return self.copy_(noise['eik_uniform'])
+
+    torch.rand, torch.randperm, torch.randint, torch.rand_like, torch.Tensor.uniform_ = \
+        rand, randperm, randint, rand_like, uniform_
+    try:
+        yield
+    finally:
+        torch.rand, torch.randperm, torch.randint, torch.rand_like, torch.Tensor.uniform_ = saved
+
+
+@contextlib.contextmanager
+def record_sampler(model):
+    """Records what the reference's ErrorBoundSampler.get_z_vals computes in each round, without touching its
+    source: the values are picked up at the functions it calls (reference: model/ray_sampler.py) --
+    get_error_bound (first call of a round: sorted z, merged sdf, d*, and the error at beta0; 141-157),
+    model.density called from get_z_vals itself (the beta the bisection ended with; 168), torch.searchsorted
+    (cdf and u; 216) and torch.sort (its input holds the new samples behind the old ones; 233, 251).
+    Yields a list with one dict per round."""
+    rounds = []
+    state = {'in_eb': False, 'active': False}
+    sampler, density = model.ray_sampler, model.density
+    orig_eb, orig_dens, orig_gz = sampler.get_error_bound, density.forward, sampler.get_z_vals
+    orig_ss, orig_sort = torch.searchsorted, torch.sort
+
+    def eb(beta, mdl, sdf, z_vals, dists, d_star):
+        state['in_eb'] = True
+        try:
+            out = orig_eb(beta, mdl, sdf, z_vals, dists, d_star)
+        finally:
+            state['in_eb'] = False
+        if not rounds or 'beta' in rounds[-1]:
+            rounds.append({'z': z_vals.detach().clone(), 'sdf': sdf.detach().reshape(z_vals.shape).clone(),
+                           'dstar': d_star.detach().clone(), 'err0': out.detach().clone()})
+        return out
+
+    def dens(sdf, beta=None):
+        out = orig_dens(sdf, beta=beta)
+        if state['active'] and not state['in_eb'] and beta is not None:
+            rounds[-1]['beta'] = beta.detach().reshape(-1).clone()
+        return out
+
+    def searchsorted(cdf, u, **kw):
+        if state['active']:
+            rounds[-1]['cdf'] = cdf.detach().clone()
+            rounds[-1]['u'] = u.detach().clone()
+        return orig_ss(cdf, u, **kw)
+
+    def sort(t, *a, **kw):
+        if state['active'] and 'cdf' in rounds[-1] and 'samples' not in rounds[-1]:
+            n_new = rounds[-1]['u'].shape[1]
+            m = rounds[-1]['z'].shape[1]
+            # continuing round: cat([z_vals, samples]); last round: cat([z_samples, near, far, extra])
+            rounds[-1]['samples'] = (t[:, m:m + n_new] if t.shape[1] == m + n_new else t[:, :n_new]).detach().clone()
+        return orig_sort(t, *a, **kw)
+
+    def get_z_vals(*a, **kw):
+        state['active'] = True
+        try:
+            return orig_gz(*a, **kw)
+        finally:
+            state['active'] = False
+
+    sampler.get_error_bound, density.forward, sampler.get_z_vals = eb, dens, get_z_vals
+    torch.searchsorted, torch.sort = searchsorted, sort
+    try:
+        yield rounds
+    finally:
+        del sampler.get_error_bound, density.forward, sampler.get_z_vals
+        torch.searchsorted, torch.sort = orig_ss, orig_sort
 
 
 def noise_from_log(log, n_extra=32):

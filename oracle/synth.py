@@ -39,8 +39,12 @@ def color_in_dim(conf):
     return d
 
 
-def make_state(conf, seed=0, jitter=0.0, dtype=torch.float32):
-    """State dict (reference key names) for ``conf``; numpy default_rng(seed)."""
+def make_state(conf, seed=0, jitter=0.0, dtype=torch.float32, sdf_scale=1.0):
+    """State dict (reference key names) for ``conf``; numpy default_rng(seed).
+
+    ``sdf_scale`` multiplies the sdf row of the last SDF layer (its weight_g and bias): values below 1 make
+    |sdf| under-estimate the distance to the surface, which is what keeps the error-bounded sampler from
+    converging (4, 5 rounds and the exit at max_total_iters)."""
     from .hashgrid_oracle import level_geometry
     rng = np.random.default_rng(seed)
     ic = conf['implicit_network']
@@ -99,6 +103,14 @@ def make_state(conf, seed=0, jitter=0.0, dtype=torch.float32):
         st['rendering_network.embeddings'] = rng.uniform(-1e-4, 1e-4, size=(1024, 32))
     st['density.beta'] = np.asarray(conf['density']['params_init']['beta'], dtype=np.float64)
 
+    if sdf_scale != 1.0:
+        last = 'implicit_network.lin%d' % (n_lin - 1)
+        st[last + '.bias'] = st[last + '.bias'].copy()
+        st[last + '.bias'][0] *= sdf_scale
+        key = last + ('.weight_g' if ic.get('weight_norm', True) else '.weight')
+        st[key] = st[key].copy()
+        st[key][0] *= sdf_scale
+
     out = {}
     for k, v in st.items():
         t = torch.from_numpy(np.ascontiguousarray(v))
@@ -143,3 +155,36 @@ def make_noise(conf, n_rays, n_dense, seed=2, dtype=torch.float32):
         'eik_uniform': t(rng.uniform(-r, r, size=(n_rays, 3))),
         'nei_rand': t(rng.uniform(size=(2 * n_rays, 3))),
     }
+
+
+def make_noise_table(conf, n_rays, seed=2, dtype=torch.float32):
+    """make_noise for a call whose number of sampler rounds is not known in advance: 'extra_idx' is a table
+    [max_total_iters, N_samples_extra] whose row k-1 holds the columns for a dense set of 128 k samples."""
+    sc = conf['ray_sampler']
+    noise = make_noise(conf, n_rays, sc['N_samples_eval'], seed, dtype)
+    rows = []
+    for k in range(sc['max_total_iters']):
+        rng = np.random.default_rng(seed * 131 + 7 * k + 1)
+        rows.append(rng.permutation(sc['N_samples_eval'] * (k + 1))[:sc['N_samples_extra']].astype(np.int64))
+    noise['extra_idx'] = torch.from_numpy(np.stack(rows))
+    return noise
+
+
+def analytic_targets(rays, radius=0.6):
+    """Supervision for the training-trajectory fixture, a closed-form scene so that nothing but seeds has to be
+    stored: the rays (origins inside) hit the inside of a sphere of `radius`; colour is a smooth function of the hit
+    point, the depth cue is the hit distance up to the monocular scale, the normal cue the sphere's inward normal
+    in the camera frame.  Shapes as the reference's data loader delivers them ([1, N, C])."""
+    o, d = rays['ray_cam_loc'].double(), rays['ray_dirs'].double()
+    b = (o * d).sum(-1)
+    c = (o * o).sum(-1) - radius * radius
+    t = -b + torch.sqrt(b * b - c)
+    p = o + t.unsqueeze(-1) * d
+    rgb = 0.5 + 0.4 * torch.sin(3.0 * p + torch.tensor([0.0, 1.0, 2.0], dtype=torch.float64))
+    n_world = -p / radius
+    rot = rays['ray_pose'][:, :3, :3].double().transpose(1, 2)
+    n_cam = (rot @ n_world.unsqueeze(-1)).squeeze(-1)
+    depth = t * rays['ray_dirs_tmp'][:, 2].double().abs()
+    f = lambda a: a.float()[None]
+    return {'rgb': f(rgb), 'depth': f((depth / 50.0).unsqueeze(-1)), 'normal': f(n_cam),
+            'mask': torch.ones(1, o.shape[0], 1)}

@@ -24,7 +24,7 @@ def run(split_fn, label, iters=5):
     st = _lib.stream_ptr()
     macs = sum(it['wx'] * it['wy'] for it in prog.items) * P_pad
     def once():
-        _lib.call('msdf_wgrad', _lib.ptr(items), _lib.ptr(wg_map), wg_map.numel() // 2, None, _lib.ptr(part), P_pad, PREC, st)
+        _lib.call('msdf_wgrad', _lib.ptr(items), _lib.ptr(wg_map), wg_map.numel() // 2, _lib.ptr(part), P_pad, PREC, st)
     once(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

@@ -17,3 +17,30 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+# Measured errors of the GPU parity tests: every comparison calls errlog(test, case, key, err, tol); the table is
+# written to gpurun_out/parity_errors.json at the end of the session (scripts/parity_table.py turns it into
+# profiles/rNN_parity_errors.md -- the tolerances in the tests are ratcheted against it).
+_ERRLOG = []
+
+
+@pytest.fixture(scope='session')
+def errlog():
+    def log(test, case, key, err, tol):
+        _ERRLOG.append({'test': test, 'case': case, 'key': key, 'err': float(err), 'tol': float(tol)})
+        return float(err)
+    return log
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _ERRLOG:
+        return
+    import json
+    out = os.path.join(ROOT, 'gpurun_out')
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, 'parity_errors.json'), 'w') as f:
+            json.dump(_ERRLOG, f, indent=0)
+    except OSError:
+        pass

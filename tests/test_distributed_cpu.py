@@ -85,3 +85,207 @@ def test_shard_slice_is_a_partition():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def _run_workers(target, world=2, timeout=300, args=()):
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + tuple(args)) for r in range(world)]
+    for p in procs:
+        p.start()
+    import queue
+    import time
+    t0, res = time.time(), None
+    while res is None:
+        try:
+            res = q.get(timeout=1.0)
+        except queue.Empty:
+            if any(p.exitcode not in (None, 0) for p in procs) or time.time() - t0 > timeout:
+                for p in procs:
+                    p.kill()
+                raise AssertionError('a rank failed (exit codes %r)' % [p.exitcode for p in procs])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def _setup(rank, world, port):
+    import sys
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    torch.set_num_threads(2)
+
+
+class _OracleImageModel:
+    """Stands in for MonoSDFNetwork in image mode (the distributed drivers only call it and toggle .training)."""
+
+    def __init__(self, state, conf):
+        self.state, self.conf, self.training, self.calls = state, conf, True, []
+
+    def eval(self):
+        self.training = False
+
+    def train(self, mode=True):
+        self.training = mode
+
+    def __call__(self, inputs, indices):
+        from oracle import monosdf_oracle as mo
+        assert not self.training
+        self.calls.append(inputs['uv'].shape[1])
+        with torch.enable_grad():        # the oracle takes d sdf / dx by autograd; the HIP model has it in-kernel
+            out = mo.render(self.state, self.conf, inputs, indices, False, False, None)
+        return {k: v.detach() for k, v in out.items()}
+
+
+def _render_worker(rank, world, port, q):
+    _setup(rank, world, port)
+    try:
+        from monosdf_amd.utils import render
+        from oracle import config, monosdf_oracle as mo, synth
+        conf = config.mlp_config(64)
+        state = synth.make_state(conf, seed=0, jitter=0.2)
+        total, split = 73, 10                       # 8 chunks, the last one ragged (3 pixels) and on rank 1
+        g = torch.Generator().manual_seed(5)
+        uv = torch.rand(1, total, 2, generator=g) * 384
+        intr = torch.eye(4)[None].clone()
+        intr[0, 0, 0], intr[0, 1, 1], intr[0, 0, 2], intr[0, 1, 2] = 300., 310., 192., 190.
+        pose = torch.eye(4)[None].clone()
+        pose[0, :3, 3] = torch.tensor([0.1, -0.15, 0.05])
+        inputs = {'uv': uv, 'pose': pose, 'intrinsics': intr}
+        model = _OracleImageModel(state, conf)
+        out = render.render_image(model, inputs, torch.tensor([3]), total, split_n_pixels=split)
+        assert model.training                       # mode restored
+        # chunk c -> rank c mod world (SURVEY 8(e)): this rank rendered exactly its chunks
+        sizes = [min(split, total - c * split) for c in range((total + split - 1) // split)]
+        assert model.calls == [sizes[c] for c in range(rank, len(sizes), world)]
+        ref = mo.render_image(state, conf, inputs, torch.tensor([3]), total, split_n_pixels=split)
+        err = max((out[k] - ref[k]).abs().max().item() for k in ref)
+        shapes_ok = all(out[k].shape == ref[k].shape for k in ref)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (err, shapes_ok))
+        if rank == 0:
+            q.put(gathered)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_render_image_two_ranks_equals_single_process():
+    """configs[3] plumbing: chunks dealt round-robin over 2 ranks (ragged last chunk), one all-gather, rows put
+    back in pixel order -- every rank ends with the image a single process renders."""
+    for err, shapes_ok in _run_workers(_render_worker):
+        assert shapes_ok and err == 0.0
+
+
+def _volume_worker(rank, world, port, q):
+    _setup(rank, world, port)
+    try:
+        from monosdf_amd.utils import render
+        from oracle import config, monosdf_oracle as mo, synth
+        conf = config.mlp_config(64)
+        state = synth.make_state(conf, seed=0, jitter=0.3)
+        calls = []
+
+        def sdf_fn(p):
+            calls.append(p.shape[0])
+            with torch.no_grad():
+                return mo.sdf_network_raw(state, conf, p)[:, 0]
+        blocks = list(render.sdf_volume(sdf_fn, resolution=128, grid_boundary=(-1.1, 1.1), device='cpu', shard=True))
+        assert len(blocks) == 1
+        vol = torch.from_numpy(blocks[0][2])
+        n_eval = sum(calls)
+        if rank == 0:
+            ref_calls = []
+
+            def ref_fn(p):
+                ref_calls.append(p.shape[0])
+                with torch.no_grad():
+                    return mo.sdf_network_raw(state, conf, p)[:, 0]
+            ref = mo.sdf_volume_block(ref_fn, (-1.1,) * 3, (1.1,) * 3, 128)
+            q.put((bool(torch.equal(vol, ref)), n_eval, sum(ref_calls)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sdf_volume_sharded_equals_single_process():
+    """configs[4] plumbing: every pyramid level's (masked) point list is cut evenly over the ranks and the values
+    are all-gathered; the volume equals the single-process one bit for bit, at half the evaluations per rank."""
+    same, n_rank0, n_single = _run_workers(_volume_worker)
+    assert same
+    assert abs(n_rank0 - n_single / 2) <= 4         # one point per level of imbalance at most
+
+
+def _rounds_worker(rank, world, port, q):
+    _setup(rank, world, port)
+    try:
+        sys_path = os.path.join(os.path.dirname(os.path.abspath(__file__)))
+        import sys
+        sys.path.insert(0, sys_path)
+        from helpers import Case
+        from monosdf_amd import parallel
+        from oracle import monosdf_oracle as mo
+        c = Case('mlp_w64_eval_k5')                  # the whole batch needs 5 rounds, its second half alone 3
+        rays = c.inputs
+        n = rays['ray_dirs'].shape[0]
+        lo, hi = parallel.shard_slice(n)
+        d, o = rays['ray_dirs'][lo:hi], rays['ray_cam_loc'][lo:hi]
+
+        def all_max(t):
+            t = t.clone()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return t
+        alone, together = {}, {}
+        z_alone, _ = mo.error_bound_sampler(c.state, c.conf, d, o, False, None, trace=alone)
+        z_glob, _ = mo.error_bound_sampler(c.state, c.conf, d, o, False, None, trace=together, max_reduce=all_max)
+        full = parallel.all_gather_rows(z_glob)
+        info = [None] * world
+        dist.all_gather_object(info, (alone['rounds'], together['rounds']))
+        if rank == 0:
+            q.put((info, bool(torch.equal(full, c.out['z_vals'])), c.rounds))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_global_round_decision_reproduces_single_process_rounds():
+    """SURVEY 8(e), strong scaling: with the max beta all-reduced (MAX) before each round's convergence test, every
+    shard runs the rounds the whole batch runs on one process and the gathered z equal the reference's z for the
+    whole batch; left alone, a shard stops as soon as ITS rays have converged."""
+    info, same, rounds = _run_workers(_rounds_worker)
+    assert all(t == rounds for _, t in info)
+    assert same
+    assert any(a < rounds for a, _ in info)         # the protocol matters: some shard would have stopped early
+
+
+def _averager_worker(rank, world, port, q):
+    _setup(rank, world, port)
+    try:
+        from monosdf_amd import parallel
+        torch.manual_seed(0)
+        params = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7)),
+                  torch.nn.Parameter(torch.randn(2, 2), requires_grad=False), torch.nn.Parameter(torch.randn(4))]
+        avg = parallel.GradientAverager(params)
+        ok = True
+        for step in range(3):
+            for p in params:
+                p.grad = None
+            params[0].grad = torch.full((5, 3), float(rank + 1 + step))
+            if rank == 0:                            # this parameter has a gradient on one rank only
+                params[1].grad = torch.full((7,), 2.0)
+            flat = avg.average()
+            ok &= bool(torch.all(params[0].grad == (1 + 2) / 2 + step))
+            ok &= bool(torch.all(params[1].grad == 1.0))
+            ok &= params[2].grad is None and bool(torch.all(params[3].grad == 0))
+            ok &= params[0].grad.data_ptr() == flat.data_ptr()          # views of the persistent buffer
+        res = [None] * world
+        dist.all_gather_object(res, ok)
+        if rank == 0:
+            q.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_averager_fixed_layout_and_persistent_buffer():
+    """same layout on every rank even when a gradient is missing on one of them; no per-step buffer."""
+    assert all(_run_workers(_averager_worker))

@@ -160,3 +160,53 @@ def test_fullsize_hash_grid_linearity_and_adjointness():
     # coarsest levels: every one of their entries receives gradient from ~100k points
     n0 = int(enc.offsets[2].item())
     assert (ga[:n0].abs().sum(1) > 0).float().mean().item() > 0.5
+
+
+def test_fullsize_binned_scatter_equals_atomic_scatter():
+    """configs[2] size (104,448 points, 16 x 2, 2^19 entries per hashed level): the binned scatter (crowded bins are
+    cut over several workgroups, the coarse levels hold hundreds of contributions per entry) against the
+    one-atomic-per-corner kernels, first order, second order and both fused."""
+    from monosdf_amd import _lib
+    from monosdf_amd.hashencoder.hashgrid import HashEncoder
+    enc = HashEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19,
+                      desired_resolution=2048).cuda()
+    B, L, C = N * 102, 16, 2
+    g = torch.Generator(device='cuda').manual_seed(6)
+    # half of the points on 64 "rays" through a small region (crowded cells on every level), half anywhere
+    t = torch.rand(B // 2, 1, device='cuda', generator=g)
+    o = torch.rand(64, 3, device='cuda', generator=g)[torch.randint(64, (B // 2,), device='cuda', generator=g)]
+    x = torch.cat([0.45 + 0.1 * (o + t * 0.3), torch.rand(B - B // 2, 3, device='cuda', generator=g)]).contiguous()
+    grad = torch.randn(L, B, C, device='cuda', generator=g)
+    grad2 = torch.randn(L, B, C, device='cuda', generator=g)
+    gg = torch.randn(B, 3, device='cuda', generator=g)
+    emb, offs = enc.embeddings.detach(), enc.offsets
+    n = emb.shape[0]
+    S, H = enc.log2_scale, int(enc.base_resolution)
+    st = _lib.stream_ptr()
+    dy = torch.empty(B, L * 3 * C, device='cuda')
+    out = torch.empty(L, B, C, device='cuda')
+    _lib.call('msdf_hash_encode_forward', _lib.ptr(x), _lib.ptr(emb), _lib.ptr(offs), _lib.ptr(out), B, 3, C, L, S, H, 1,
+              _lib.ptr(dy), st)
+    a1, a2 = torch.zeros_like(emb), torch.zeros_like(emb)
+    gi, ggrad = torch.zeros_like(x), torch.zeros(L, B, C, device='cuda')
+    _lib.call('msdf_hash_encode_backward', _lib.ptr(grad), _lib.ptr(x), _lib.ptr(emb), _lib.ptr(offs), _lib.ptr(a1),
+              B, 3, C, L, S, H, 0, _lib.ptr(dy), _lib.ptr(gi), st)
+    _lib.call('msdf_hash_encode_second_backward', _lib.ptr(grad2), _lib.ptr(x), _lib.ptr(emb), _lib.ptr(offs), B, 3, C, L,
+              S, H, 1, _lib.ptr(dy), _lib.ptr(gg), _lib.ptr(ggrad), _lib.ptr(a2), st)
+    nbytes = _lib.load().msdf_hash_scatter_workspace_bytes(B, C, L, n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+    b1, b2, bf = torch.zeros_like(emb), torch.zeros_like(emb), torch.zeros_like(emb)
+    _lib.call('msdf_hash_encode_backward_ws', _lib.ptr(grad), _lib.ptr(x), _lib.ptr(emb), _lib.ptr(offs), _lib.ptr(b1),
+              B, 3, C, L, S, H, 0, _lib.ptr(dy), None, n, _lib.ptr(ws), nbytes, st)
+    _lib.call('msdf_hash_encode_second_backward_ws', _lib.ptr(grad2), _lib.ptr(x), _lib.ptr(emb), _lib.ptr(offs), B, 3, C,
+              L, S, H, 1, _lib.ptr(dy), _lib.ptr(gg), None, _lib.ptr(b2), n, _lib.ptr(ws), nbytes, st)
+    _lib.call('msdf_hash_encode_backward_fused', _lib.ptr(grad), _lib.ptr(grad2), _lib.ptr(x), _lib.ptr(offs), _lib.ptr(bf),
+              B, 3, C, L, S, H, _lib.ptr(gg), n, _lib.ptr(ws), nbytes, st)
+    rel = lambda a, b: ((a - b).abs().max() / b.abs().max()).item()
+    assert a1.abs().max().item() > 0 and a2.abs().max().item() > 0
+    # both sides sum thousands of signed fp32 terms per crowded entry in an arbitrary order: 1e-4 of the largest entry
+    assert rel(b1, a1) < 1e-4, rel(b1, a1)
+    assert rel(b2, a2) < 1e-4, rel(b2, a2)
+    assert rel(bf, a1 + a2) < 1e-4, rel(bf, a1 + a2)
+    # per level: same support (an entry is touched by the binned path exactly when the atomics touch it)
+    assert torch.equal(b1 != 0, a1 != 0)

@@ -1,0 +1,317 @@
+"""GPU parity of the sampler kernels alone: every round of msdf_sampler_beta / msdf_sampler_resample is driven
+with the sorted samples and the SDF values the REFERENCE had at that round (recorded inside its get_z_vals by
+oracle/ref_loader.record_sampler), so no network evaluation and no earlier round can hide or amplify an error:
+d*, the error bound at beta0, beta after the bisection, the cdf and the new samples are compared one by one.
+Plus: get_error_bound / LaplaceDensity / UniformSampler against the reference's stage vectors, and the
+speculative round count against the synchronous path."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import Case, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TRACED = ['mlp_w64_eval_k2_trace', 'mlp_w64_eval_k4', 'mlp_w64_eval_k5', 'mlp_w64_eval_k5nc', 'mlp_w64_train_k4']
+
+# measured maxima (profiles/r02_parity_errors.md) x2, absolute unless noted
+TOL_DSTAR = 2e-6        # d* of an interval (values up to ~1)
+TOL_ERR0 = 2e-5         # relative: error bound at beta0 (a max over exp() of sums, values up to 1e6)
+TOL_BETA = 1e-6         # relative: beta after 10 bisection steps
+TOL_CDF = 2e-6          # cdf in [0, 1]
+# New samples: the inverse CDF is ill conditioned in z where the cdf is flat (a rounding of the cdf moves the sample
+# by up to one interval, 0.03: the reference's OWN fp32 result is that far from exact arithmetic on these cases,
+# scripts/sampler_conditioning.py -> profiles/r02_sampler_conditioning.json) and ill conditioned in cdf where the
+# cdf is steep (bins of width ~1e-7 left by earlier rounds).  Each sample therefore has to agree with the reference
+# in ONE of the two spaces: |z - z_ref| or the distance of u from the reference cdf's value(s) at the sample, with
+# 1e-5 allowed for the reference's own rule that a bin whose cdf increment is below 1e-5 is not interpolated
+# (ray_sampler.py:225-226).  The plain z-space maximum is recorded for the table, not asserted.
+TOL_SAMPLES = 1e-5 + 2e-6
+
+
+def _cdf_residual(cdf, z, x, u):
+    """Distance of u from the reference's piecewise-linear cdf over its bins z at x: zero-width bins (repeated z)
+    make the cdf an interval there.  All [N, .] on the CPU."""
+    z, x = z.contiguous(), x.contiguous()
+    m = z.shape[1]
+    lo_i = torch.searchsorted(z, x, right=False)
+    hi_i = torch.searchsorted(z, x, right=True)
+    # x strictly inside a bin: interpolate; x on one or more bin edges: [cdf of the first, cdf of the last]
+    a = (hi_i - 1).clamp(0, m - 1)
+    b = hi_i.clamp(0, m - 1)
+    z0, z1 = torch.gather(z, 1, a), torch.gather(z, 1, b)
+    c0, c1 = torch.gather(cdf, 1, a), torch.gather(cdf, 1, b)
+    lin = c0 + (x - z0) / (z1 - z0).clamp(min=1e-30) * (c1 - c0)
+    on_edge = hi_i > lo_i
+    lo = torch.where(on_edge, torch.gather(cdf, 1, lo_i.clamp(0, m - 1)), lin)
+    hi = torch.where(on_edge, torch.gather(cdf, 1, (hi_i - 1).clamp(0, m - 1)), lin)
+    return torch.maximum(lo - u, u - hi).clamp(min=0)
+
+
+def _model(case):
+    from monosdf_amd.conf import ConfigTree
+    from monosdf_amd.model.network import MonoSDFNetwork
+    m = MonoSDFNetwork(ConfigTree.from_dict(case.conf))
+    m.load_state_dict({k: v.clone() for k, v in case.state.items()}, strict=True)
+    m.train(case.training)
+    return m.cuda()
+
+
+@pytest.mark.parametrize('name', TRACED)
+def test_sampler_rounds_with_reference_sdf(name, errlog):
+    from monosdf_amd import _lib
+    from oracle import monosdf_oracle as mo
+    c = Case(name)
+    sc = c.conf['ray_sampler']
+    n_eval, n_final, K = sc['N_samples_eval'], sc['N_samples'], sc['max_total_iters']
+    m_max = n_eval * K
+    rays = c.inputs
+    N = rays['ray_dirs'].shape[0]
+    dev = 'cuda'
+    f32 = dict(device=dev, dtype=torch.float32)
+    ray_o, ray_d = rays['ray_cam_loc'].cuda().contiguous(), rays['ray_dirs'].cuda().contiguous()
+    beta0 = mo.get_beta(c.state, c.conf).float().reshape(1).cuda()
+    sampler_far = mo.sampler_far(c.conf)
+    assert len(c.trace) == c.rounds
+    for r, t in enumerate(c.trace):
+        M = n_eval * (r + 1)
+        assert t['z'].shape == (N, M)
+        z = torch.zeros(N, m_max, **f32)
+        sdf = torch.zeros(N, m_max, **f32)
+        z[:, :M], sdf[:, :M] = t['z'].cuda(), t['sdf'].cuda()
+        # the scatter of "new" sdf values becomes the identity on the first n_eval columns
+        new_pos = torch.arange(n_eval, device=dev, dtype=torch.int32).repeat(N, 1).contiguous()
+        new_sdf = sdf[:, :n_eval].contiguous()
+        if r == 0:
+            d = t['z'][:, 1:] - t['z'][:, :-1]
+            lemma = 1.0 / (4.0 * torch.log(torch.tensor(sc['eps'] + 1.0)))
+            beta_in = torch.sqrt(lemma * (d ** 2.).sum(-1))          # ray_sampler.py:118-120
+        else:
+            beta_in = c.trace[r - 1]['beta']
+        beta = beta_in.clone().cuda().contiguous()
+        flags = torch.zeros(2 * K, device=dev, dtype=torch.int32)
+        if r > 0:
+            flags[2 * (r - 1) + 1] = 1
+        new_z = torch.zeros(N, n_eval, **f32)
+        pts = torch.zeros(N * n_eval, 3, **f32)
+        final_z = torch.zeros(N, n_final, **f32)
+        dbg_dstar, dbg_cdf = torch.zeros(N, m_max, **f32), torch.zeros(N, m_max, **f32)
+        dbg_err0 = torch.zeros(N, **f32)
+        last = r + 1 == c.rounds
+        u_final = t['u'].cuda().contiguous() if (last and c.training) else None
+        a = _lib.SamplerArgs()
+        a.ray_o, a.ray_d, a.N, a.M, a.m_max = ray_o.data_ptr(), ray_d.data_ptr(), N, M, m_max
+        a.n_eval, a.n_final, a.n_extra = n_eval, n_final, sc['N_samples_extra']
+        a.round_idx, a.max_rounds, a.training, a.beta_iters = r, K, int(c.training), sc['beta_iters']
+        a.near, a.far, a.bound = float(sc['near']), float(sampler_far), float(c.conf['scene_bounding_sphere'])
+        a.eps, a.add_tiny = float(sc['eps']), 1e-6
+        a.lemma = float(1.0 / (4.0 * torch.log(torch.tensor(sc['eps'] + 1.0))))
+        a.beta0, a.z, a.sdf = beta0.data_ptr(), z.data_ptr(), sdf.data_ptr()
+        a.new_z, a.new_sdf, a.new_pos = new_z.data_ptr(), new_sdf.data_ptr(), new_pos.data_ptr()
+        a.pts, a.beta, a.flags = pts.data_ptr(), beta.data_ptr(), flags.data_ptr()
+        a.u_final = u_final.data_ptr() if u_final is not None else None
+        a.final_z = final_z.data_ptr()
+        a.dbg_dstar, a.dbg_err0, a.dbg_cdf = dbg_dstar.data_ptr(), dbg_err0.data_ptr(), dbg_cdf.data_ptr()
+        st = _lib.stream_ptr()
+        _lib.call('msdf_sampler_beta', C.byref(a), st)
+        _lib.call('msdf_sampler_resample', C.byref(a), st)
+        torch.cuda.synchronize()
+        tag = 'r%d' % r
+        e = errlog('sampler_rounds', name, tag + '.dstar', (dbg_dstar[:, :M - 1].cpu() - t['dstar']).abs().max(), TOL_DSTAR)
+        assert e <= TOL_DSTAR, (tag, 'dstar', e)
+        e = errlog('sampler_rounds', name, tag + '.err0',
+                   ((dbg_err0.cpu() - t['err0']).abs() / t['err0'].abs().clamp(min=1e-3)).max(), TOL_ERR0)
+        assert e <= TOL_ERR0, (tag, 'err0', e)
+        e = errlog('sampler_rounds', name, tag + '.beta', ((beta.cpu() - t['beta']).abs() / t['beta']).max(), TOL_BETA)
+        assert e <= TOL_BETA, (tag, 'beta', e)
+        # the batch-global decision: another round unless converged or at max_total_iters
+        assert int(flags[2 * r + 1]) == int(not last), tag
+        assert np.float32(flags[2 * r].cpu().numpy().view(np.float32)) == np.float32(beta.max().item())
+        e = errlog('sampler_rounds', name, tag + '.cdf', (dbg_cdf[:, :M].cpu() - t['cdf']).abs().max(), TOL_CDF)
+        assert e <= TOL_CDF, (tag, 'cdf', e)
+        got = (final_z if last else new_z).cpu()
+        assert got.shape == t['samples'].shape
+        assert float(got.min()) >= float(t['z'].min()) and float(got.max()) <= float(t['z'].max())
+        in_z = (got - t['samples']).abs()
+        in_cdf = _cdf_residual(t['cdf'], t['z'], got, t['u'])
+        e = errlog('sampler_rounds', name, tag + '.samples (z or cdf space)', torch.minimum(in_z, in_cdf).max(),
+                   TOL_SAMPLES)
+        assert e <= TOL_SAMPLES, (tag, 'samples', e)
+        errlog('sampler_rounds', name, tag + '.samples (z space, not asserted)', (got - t['samples']).abs().max(),
+               float('inf'))
+        if not last:
+            # the merged set the next round starts from: exactly the sorted union of the old and the new samples,
+            # every new sample at the position the kernel reported, its point on the ray
+            both, _ = torch.sort(torch.cat([t['z'], got], 1), 1)
+            assert torch.equal(z[:, :M + n_eval].cpu(), both)
+            pos = new_pos.cpu().long()
+            assert torch.equal(torch.gather(z[:, :M + n_eval].cpu(), 1, pos), got)
+            want = ray_o.unsqueeze(1) + new_z.unsqueeze(2) * ray_d.unsqueeze(1)
+            assert torch.allclose(pts.reshape(N, n_eval, 3), want, rtol=0, atol=1e-6)
+
+
+def test_inactive_rounds_do_nothing():
+    """A round whose predecessor did not ask for it leaves every buffer untouched (what makes enqueueing too
+    many rounds harmless)."""
+    from monosdf_amd import _lib
+    c = Case('mlp_w64_eval_k2_trace')
+    sc = c.conf['ray_sampler']
+    n_eval, K = sc['N_samples_eval'], sc['max_total_iters']
+    N, m_max = 6, n_eval * K
+    g = torch.Generator().manual_seed(0)
+    bufs = {k: torch.rand(*shape, generator=g).cuda() for k, shape in
+            dict(z=(N, m_max), sdf=(N, m_max), new_z=(N, n_eval), new_sdf=(N, n_eval), pts=(N * n_eval, 3),
+                 beta=(N,), final_z=(N, sc['N_samples']), o=(N, 3), d=(N, 3), beta0=(1,)).items()}
+    new_pos = torch.arange(n_eval, dtype=torch.int32).repeat(N, 1).cuda()
+    flags = torch.zeros(2 * K, dtype=torch.int32).cuda()           # round 0 did not set flags[1]
+    before = {k: v.clone() for k, v in bufs.items()}
+    a = _lib.SamplerArgs()
+    a.ray_o, a.ray_d, a.N, a.M, a.m_max = bufs['o'].data_ptr(), bufs['d'].data_ptr(), N, 2 * n_eval, m_max
+    a.n_eval, a.n_final, a.n_extra = n_eval, sc['N_samples'], sc['N_samples_extra']
+    a.round_idx, a.max_rounds, a.training, a.beta_iters = 1, K, 0, sc['beta_iters']
+    a.near, a.far, a.bound, a.eps, a.add_tiny, a.lemma = 0.0, 3.85, 1.1, 0.1, 1e-6, 2.6
+    a.beta0, a.z, a.sdf = bufs['beta0'].data_ptr(), bufs['z'].data_ptr(), bufs['sdf'].data_ptr()
+    a.new_z, a.new_sdf, a.new_pos = bufs['new_z'].data_ptr(), bufs['new_sdf'].data_ptr(), new_pos.data_ptr()
+    a.pts, a.beta, a.flags, a.final_z = bufs['pts'].data_ptr(), bufs['beta'].data_ptr(), flags.data_ptr(), \
+        bufs['final_z'].data_ptr()
+    _lib.call('msdf_sampler_beta', C.byref(a), _lib.stream_ptr())
+    _lib.call('msdf_sampler_resample', C.byref(a), _lib.stream_ptr())
+    torch.cuda.synchronize()
+    for k in bufs:
+        assert torch.equal(bufs[k], before[k]), k
+    assert int(flags.abs().sum()) == 0
+
+
+def test_error_bound_density_uniform_stage_vectors(golden_dir, errlog):
+    """get_error_bound, LaplaceDensity (scalar and per-ray beta) and UniformSampler against the vectors recorded
+    from the reference's own sub-modules (tests/golden/stages.npz: eb.*, dens.*, uni.*, cube.*)."""
+    from monosdf_amd.model.density import LaplaceDensity
+    from monosdf_amd.model.ray_sampler import ErrorBoundSampler, UniformSampler
+    zf = np.load(golden_dir + '/stages.npz')
+    t = lambda k: torch.from_numpy(zf[k]).cuda()
+    s, b = t('dens.sdf'), t('dens.beta')
+    dens = LaplaceDensity(params_init={'beta': 0.1}, beta_min=0.0001).cuda()
+    assert abs(dens.get_beta().item() - float(zf['dens.get_beta'])) == 0.0
+    e = errlog('stages', 'stages', 'dens.scalar', rel_err(dens(s), t('dens.scalar')), 1e-6)
+    assert e < 1e-6
+    e = errlog('stages', 'stages', 'dens.perray', rel_err(dens(s, beta=b), t('dens.perray')), 1e-6)
+    assert e < 1e-6
+    # gradients of the density operator against autograd on the reference formula
+    s_g, b_g = s.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    w = torch.randn(s.shape, generator=torch.Generator().manual_seed(1)).cuda()
+    (w * dens(s_g, beta=b_g)).sum().backward()
+    s_r, b_r = s.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    (w * ((1 / b_r) * (0.5 + 0.5 * s_r.sign() * torch.expm1(-s_r.abs() / b_r)))).sum().backward()
+    assert rel_err(s_g.grad, s_r.grad) < 1e-5 and rel_err(b_g.grad, b_r.grad) < 1e-5
+    smp = ErrorBoundSampler(1.1, near=0.0, N_samples=64, N_samples_eval=128, N_samples_extra=32, eps=0.1,
+                            beta_iters=10, max_total_iters=5)
+    zz = t('eb.z')
+    eb = smp.get_error_bound(b, None, s.reshape(-1, 1), zz, zz[:, 1:] - zz[:, :-1], t('eb.dstar'))
+    ref = t('eb.out')
+    e = errlog('stages', 'stages', 'eb.out', ((eb - ref).abs() / ref.abs().clamp(min=1e-6)).max(), 1e-5)
+    assert e < 1e-5, e
+
+    class M:                      # the samplers only look at .training
+        training = False
+    us = UniformSampler(1.1, 0.0, 128, take_sphere_intersection=True)
+    z, near, far = us.get_z_vals(t('uni.d'), t('uni.o'), M)
+    e = errlog('stages', 'stages', 'uni.z_eval', (z - t('uni.z_eval')).abs().max(), 1e-6)
+    assert e <= 1e-6 and torch.equal(near, torch.zeros_like(near))
+    assert (far - t('uni.far')).abs().max() <= 1e-6
+    M.training = True
+    z, _, _ = us.get_z_vals(t('uni.d'), t('uni.o'), M, jitter=t('uni.jitter'))
+    e = errlog('stages', 'stages', 'uni.z_train', (z - t('uni.z_train')).abs().max(), 1e-6)
+    assert e <= 1e-6
+    M.training = False
+    # rays that miss / graze the cube (near_far_from_cube, ray_sampler.py:48-60): far only (near is the constant)
+    _, _, far = UniformSampler(1.1, 0.0, 8, take_sphere_intersection=True).get_z_vals(t('cube.d'), t('cube.o'), M)
+    assert (far - t('cube.far')).abs().max() <= 1e-6 * 3.85
+    # take_sphere_intersection=False: the constant far = 2 R 1.75
+    z, near, far = UniformSampler(1.1, 0.0, 64).get_z_vals(t('uni.d'), t('uni.o'), M)
+    assert torch.equal(far, torch.full_like(far, 3.85)) and z.shape == (10, 64)
+    assert torch.allclose(z[:, -1], far[:, 0]) and torch.equal(z[:, 0], torch.zeros(10).cuda())
+
+
+def _run(model, case, rounds_hint, speculate):
+    from oracle import monosdf_oracle as mo
+    model.speculate_rounds = speculate
+    model.ray_sampler._history = [rounds_hint] if rounds_hint else []
+    model.ray_sampler.last_rounds = rounds_hint
+    model.zero_grad(set_to_none=True)
+    model._noise = {k: v.cuda() for k, v in case.noise.items()} if case.noise else None
+    out = model({k: v.cuda() for k, v in case.inputs.items()}, case.indices.cuda(), if_pixel_input=case.pixel)
+    grads = None
+    if case.training:
+        mo.probe_loss(out).backward()
+        grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    return {k: v.detach().clone() for k, v in out.items()}, grads
+
+
+@pytest.mark.parametrize('name,hint', [('mlp_w64_train', 3), ('mlp_w64_train', 5), ('mlp_w64_eval', 4),
+                                       ('mlp_w64_train_k4', 1), ('mlp_w64_train_k4', 5), ('mlp_w64_eval_k3', 1),
+                                       ('mlp_w64_eval_k3', 2), ('mlp_w64_train_k5nc', 2)])
+def test_speculated_rounds_equal_synchronous_path(name, hint):
+    """the round count guessed from earlier calls may be too large (rounds that the flags did not ask
+    for are enqueued) or too small (the pass is repeated).  Either way outputs AND gradients must be bit-identical
+    to the path that reads the flag after every round."""
+    c = Case(name)
+    m = _model(c)
+    ref_out, ref_grads = _run(m, c, 0, False)
+    assert m.ray_sampler.last_rounds == c.rounds
+    stats0 = dict(m.ray_sampler.stats)
+    out, grads = _run(m, c, hint, True)
+    assert m.ray_sampler.last_rounds == c.rounds
+    d = {k: m.ray_sampler.stats[k] - stats0[k] for k in stats0}
+    if hint >= c.rounds:
+        assert d['repeats'] == 0 and d['idle_rounds'] == hint - c.rounds and d['calls'] == 1
+    else:
+        assert d['repeats'] == 1 and d['calls'] == 2
+    for k in ref_out:
+        assert torch.equal(out[k], ref_out[k]), k
+    if c.training:
+        assert set(grads) == set(ref_grads)
+        for n in ref_grads:
+            # weight gradients are bitwise reproducible (fixed-order reduction)
+            assert torch.equal(grads[n], ref_grads[n]), n
+    # the next speculative call starts from the rounds that actually ran
+    assert m.ray_sampler.guess_rounds() >= c.rounds
+
+
+def test_global_round_decision_single_rank():
+    """ErrorBoundSampler.global_rounds with a one-rank group: the all-reduce is the identity."""
+    import torch.distributed as dist
+    c = Case('mlp_w64_eval_k3')
+    m = _model(c)
+    ref, _ = _run(m, c, 0, False)
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29541')
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        m.ray_sampler.global_rounds = True
+        for spec in (False, True):
+            out, _ = _run(m, c, 3 if spec else 0, spec)
+            assert m.ray_sampler.last_rounds == c.rounds
+            for k in ref:
+                assert torch.equal(out[k], ref[k]), k
+    finally:
+        m.ray_sampler.global_rounds = None
+        if created:
+            dist.destroy_process_group()
+
+
+def test_weight_norm_backward_checks_parameter_versions():
+    """the weight-norm backward kernel re-reads weight_v / weight_g; an in-place update between forward
+    and backward must raise (autograd's version counter) instead of returning gradients of other weights."""
+    c = Case('mlp_w64_train')
+    m = _model(c)
+    x = torch.rand(64, 3, device='cuda')
+    sdf, feat, grad = m.implicit_network.get_outputs(x)
+    with torch.no_grad():
+        m.implicit_network.lin3.weight_v.mul_(1.5)
+    with pytest.raises(RuntimeError, match='modified by an inplace operation'):
+        (sdf.sum() + grad.sum()).backward()

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared_symbols():
     text = open(os.path.join(ROOT, 'include', 'monosdf_hip.h')).read()
-    return sorted(set(re.findall(r'^int (msdf_\w+)\(', text, flags=re.M)))
+    return sorted(set(re.findall(r'^(?:int|int64_t) (msdf_\w+)\(', text, flags=re.M)))
 
 
 def test_header_and_binding_agree():
@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in _declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.msdf_abi_version() == 3
+    assert lib.msdf_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_struct_sizes_match_header():

@@ -43,13 +43,38 @@ def test_forward_and_grads_match_reference(name):
 
 
 def test_sampler_round_counts():
-    for name in ['mlp_w64_eval', 'mlp_w64_eval_sharp', 'mlp_w64_eval_vsharp', 'mlp_w64_eval_maxit']:
+    seen = set()
+    for name in ['mlp_w64_eval', 'mlp_w64_eval_sharp', 'mlp_w64_eval_vsharp', 'mlp_w64_eval_k3',
+                 'mlp_w64_eval_k4', 'mlp_w64_eval_k5', 'mlp_w64_eval_k5nc', 'mlp_w64_train_k4',
+                 'mlp_w64_train_k5nc']:
         c = Case(name)
         trace = {}
         rays = c.inputs
-        mo.error_bound_sampler(c.state, c.conf, rays['ray_dirs'], rays['ray_cam_loc'], False, None,
+        mo.error_bound_sampler(c.state, c.conf, rays['ray_dirs'], rays['ray_cam_loc'], c.training, c.noise,
                                trace=trace)
         assert trace['rounds'] == c.rounds
+        beta0 = mo.get_beta(c.state, c.conf)
+        assert bool(trace['beta'].max() <= beta0) == c.converged
+        seen.add((c.rounds, c.converged))
+    # the fixtures reach every exit of the loop: 1..5 rounds converged, and max_total_iters without converging
+    assert {(k, True) for k in range(1, 6)} | {(5, False)} <= seen
+
+
+@pytest.mark.parametrize('name', ['mlp_w64_eval_k2_trace', 'mlp_w64_eval_k4', 'mlp_w64_eval_k5',
+                                  'mlp_w64_eval_k5nc', 'mlp_w64_train_k4'])
+def test_sampler_rounds_match_reference_intermediates(name):
+    """Per round: sorted z, merged sdf, d*, beta after the bisection, cdf, u, new samples -- recorded inside the
+    reference's get_z_vals (oracle/ref_loader.record_sampler) -- against the oracle's."""
+    c = Case(name)
+    trace = {}
+    rays = c.inputs
+    mo.error_bound_sampler(c.state, c.conf, rays['ray_dirs'], rays['ray_cam_loc'], c.training, c.noise,
+                           trace=trace)
+    assert len(trace['per_round']) == len(c.trace) == c.rounds
+    for got, ref in zip(trace['per_round'], c.trace):
+        for k in ('z', 'sdf', 'dstar', 'beta', 'cdf', 'u', 'samples'):
+            assert got[k].shape == ref[k].shape, k
+            assert torch.allclose(got[k], ref[k], rtol=1e-5, atol=1e-6), (k, (got[k] - ref[k]).abs().max())
 
 
 def test_stage_vectors(golden_dir):
@@ -83,3 +108,57 @@ def test_stage_vectors(golden_dir):
     assert rel_err(mo.gradient_sdf(state, conf, pts), t('net.grad_unclamped')) < 1e-5
     rgb = mo.color_network(state, conf, pts, t('net.grad'), t('col.dirs'), t('net.feat'))
     assert rel_err(rgb, t('col.rgb')) < 1e-5
+
+
+def volume_fixture(golden_dir):
+    import ast
+    z = np.load(golden_dir + '/volume_w64_128.npz')
+    spec = dict(ast.literal_eval(bytes(z['spec']).decode()))
+    conf = config.mlp_config(spec['width'], 8)
+    state = synth.make_state(conf, seed=spec['weight_seed'], jitter=spec['jitter'])
+    return z, spec, conf, state
+
+
+def volume_moments(a):
+    a = np.asarray(a, dtype=np.float64).reshape(-1)
+    return np.array([a.sum(), np.abs(a).sum(), (a * a).sum()])
+
+
+def test_sdf_volume_block_matches_reference_get_surface_sliding(golden_dir):
+    """the oracle's restatement of plots.get_surface_sliding's SDF loop against the volume the
+    REFERENCE handed to marching cubes (oracle/make_golden_volume.py; plots.py:108-205)."""
+    z, spec, conf, state = volume_fixture(golden_dir)
+    lo, hi = spec['grid_boundary']
+    with torch.no_grad():
+        vol = mo.sdf_volume_block(lambda p: mo.sdf_network_raw(state, conf, p)[:, 0], (lo,) * 3, (hi,) * 3,
+                                  spec['resolution']).numpy()
+    k = spec['stride']
+    assert np.array_equal(vol[::k, ::k, ::k], z['sub'])
+    assert np.array_equal(vol[:, :, vol.shape[0] // 2], z['plane'])
+    assert np.allclose(volume_moments(vol), z['moments'], rtol=1e-12)
+    thr = 2 * (hi - lo) / spec['resolution'] * 8 / 8
+    assert int((np.abs(vol) < thr).sum()) == int(z['near_count'])
+
+
+def plumbing_fixture(golden_dir):
+    import ast
+    z = np.load(golden_dir + '/plumbing_uniform64.npz')
+    spec = dict(ast.literal_eval(bytes(z['spec']).decode()))
+    conf = config.mlp_config(spec['width'], 8)
+    state = synth.make_state(conf, seed=spec['weight_seed'], jitter=spec['jitter'])
+    rays = synth.make_rays(spec['n_rays'], seed=spec['ray_seed'], random_pose=True)
+    return z, spec, conf, state, rays
+
+
+def test_configs0_uniform_sampler_plumbing(golden_dir):
+    """BASELINE.json configs[0]: 512 rays x 64 uniform samples, fp32 on the CPU -- the oracle's composition against
+    the reference's own UniformSampler + networks + volume_rendering (oracle/make_golden.py: run_plumbing)."""
+    z, spec, conf, state, rays = plumbing_fixture(golden_dir)
+    n = spec['n_rays']
+    out = mo.render_uniform(state, conf, rays, torch.arange(n), spec['n_samples'])
+    t = lambda k: torch.from_numpy(z[k])
+    assert out['z_vals'].shape == (512, 64) and torch.equal(out['z_vals'], t('out.z_vals'))
+    for k in ('rgb_values', 'depth_values', 'normal_map'):
+        assert rel_err(out[k], t('out.' + k)) < 1e-5, (k, rel_err(out[k], t('out.' + k)))
+    for k in ('sdf', 'weights', 'rgb'):
+        assert rel_err(out[k][::8], t('sub.' + k)) < 1e-5, k
