@@ -33,9 +33,10 @@ sys.path.insert(0, ROOT)
 N_RAYS = 1024
 N_BATCHES = 8          # ray batches cycled through by the timed steps
 # entry points timed with HIP events inside the timed region (the kernels that make up >95 % of a step)
-TIMED = {'msdf_sdf_forward', 'msdf_sdf_fwd_grad', 'msdf_sdf_backward', 'msdf_wgrad', 'msdf_reduce',
+TIMED = {'msdf_sdf_forward_if', 'msdf_sdf_fwd_grad', 'msdf_sdf_backward', 'msdf_wgrad', 'msdf_reduce',
          'msdf_color_forward', 'msdf_color_backward', 'msdf_hash_encode_forward', 'msdf_hash_encode_backward',
-         'msdf_hash_encode_second_backward'}
+         'msdf_hash_encode_second_backward', 'msdf_hash_encode_backward_ws', 'msdf_hash_encode_second_backward_ws',
+         'msdf_hash_encode_backward_fused'}
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 
 
@@ -107,19 +108,27 @@ def cpu_baseline():
     """the CPU oracle (a port of the reference's PyTorch path, pinned by tests/golden) on
     the configs[1] workload -- 1024 rays, 3 timed steady-state iterations on all host cores; plus the reference
     runner's own setting of ONE thread (monosdf_train.py:37) on a bounded sample."""
-    cores = torch.get_num_threads()
+    # "all cores": PyTorch's default thread count can exceed the CPUs this process may use (a GPU box hands 16 of
+    # its 128 to one GPU's job) and then runs slower than fewer threads: take the fastest of a few counts, measured
+    # on a quarter batch, and say which
+    most = torch.get_num_threads()
+    tried = {}
+    for t in sorted({most, min(most, 64), min(most, 32), min(most, 16)}):
+        tried[t] = _cpu_time(N_RAYS // 4, 1, t)
+    cores = max(tried, key=tried.get)
     return {'value': _cpu_time(N_RAYS, 3, cores), 'unit': 'rays/s', 'cores': cores, 'kind': 'port',
             'sample': '%d rays x 98 samples (the whole configs[1] batch), fwd+bwd, 3 timed iterations after 1 warm-up, '
-                      'fp32 PyTorch CPU oracle, sampler k=1' % N_RAYS,
-            'one_thread': {'value': _cpu_time(96, 1, 1), 'unit': 'rays/s', 'cores': 1,
-                           'sample': '96 rays x 98 samples, fwd+bwd, 1 timed iteration after 1 warm-up, '
+                      'fp32 PyTorch CPU oracle, sampler k=1; thread count = the fastest of %s on a quarter batch '
+                      '(rays/s: %s)' % (N_RAYS, sorted(tried), {k: round(v, 1) for k, v in sorted(tried.items())}),
+            'one_thread': {'value': _cpu_time(192, 1, 1), 'unit': 'rays/s', 'cores': 1,
+                           'sample': '192 rays x 98 samples, fwd+bwd, 1 timed iteration after 1 warm-up, '
                                      'torch.set_num_threads(1) as the reference runner sets it'}}
 
 
 def pmc_traffic(entry, precision):
     """HBM bytes per launch of `entry` from the committed rocprofv3 --pmc summary (FETCH_SIZE x2 + WRITE_SIZE per the
     gfx950 note of MI355X_MICROARCH.md; scripts/pmc_sum.py) -> (bytes or None, file name or None)."""
-    kernel = entry + ('_k' if precision == 'fp32' else '_b16_k')
+    kernel = entry.replace('_if', '') + ('_k' if precision == 'fp32' else '_b16_k')
     for name in ('r02_pmc_%s.json' % precision, 'r01_v8_pmc_%s.json' % precision):
         path = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(path):
@@ -156,7 +165,13 @@ def grid_report(args, kern, dt, world, rounds, loss, sampler):
             0.0, kern.get('msdf_hash_encode_forward', {}).get('launches_per_step', 1.0 + rounds) - 1.0),
         'msdf_hash_encode_backward': 524.0 * P_main + 1164.0 * P_main,            # input-bwd (d/dx) + grid-bwd
         'msdf_hash_encode_second_backward': (524.0 + 1176.0) * P_main,
+        # the fused node (ops.GridSdfFunction): d/dx only; grad_grad only; both embedding scatters in one pass
+        'msdf_hash_encode_backward_ws': 524.0 * P_main,
+        'msdf_hash_encode_second_backward_ws': 524.0 * P_main,
+        'msdf_hash_encode_backward_fused': (1164.0 + 1176.0) * P_main,
     }
+    if 'msdf_hash_encode_backward_fused' in kern:      # there the plain entry point computes d/dx only
+        per_step_bytes['msdf_hash_encode_backward'] = 524.0 * P_main
     rows = {}
     for n, b in per_step_bytes.items():
         if n in kern:
@@ -293,7 +308,7 @@ def main():
         P_main, P_eik, P_smp = N_RAYS * 98, 4 * N_RAYS, N_RAYS * 128
         F = sdf_macs_per_point()
         flops = {   # algorithmic FLOPs per launch (2 FLOP / MAC), SURVEY.md 8(d) multipliers
-            'msdf_sdf_forward': 2.0 * F * P_smp,                 # no-grad forward, 1 x F_sdf
+            'msdf_sdf_forward_if': 2.0 * F * P_smp,              # no-grad forward, 1 x F_sdf (skipped launches count too)
             'msdf_sdf_fwd_grad': 2.0 * 2 * F * (P_main + P_eik),   # forward + d/dx sweep
             'msdf_sdf_backward': 2.0 * 2 * F * (P_main + P_eik),   # p-bar = W q-bar and h-bar = W^T a-bar sweeps
         }

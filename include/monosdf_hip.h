@@ -117,6 +117,11 @@ int msdf_weightnorm_backward(const msdf_wn_layer_t* layers_dev, const int* row_l
 
 int msdf_sdf_forward(const msdf_plan_t* plan, const void* wpack, const float* bpack, const float* x,
                      const float* aux, int P, float clamp_radius, float sphere_scale, float* sdf, void* stream);
+/* the same, skipped on the device when *run_flag == 0 (run_flag may be NULL): the SDF evaluation of a sampler round
+ * that the previous round did not ask for (msdf_sampler_args_t.flags) costs a kernel start, not a network pass */
+int msdf_sdf_forward_if(const msdf_plan_t* plan, const void* wpack, const float* bpack, const float* x,
+                        const float* aux, int P, float clamp_radius, float sphere_scale, float* sdf,
+                        const uint32_t* run_flag, void* stream);
 
 typedef struct {
   const void* wpack;

@@ -150,6 +150,7 @@ _SIGNATURES = {
     'msdf_weightnorm_backward': [_P, _P, C.c_int, _P, _P, _P, _P, _P],
     'msdf_pack_weights': [C.POINTER(Plan), _P, _P, _P, _P, _P, _P, _P],
     'msdf_sdf_forward': [C.POINTER(Plan), _P, _P, _P, _P, C.c_int, C.c_float, C.c_float, _P, _P],
+    'msdf_sdf_forward_if': [C.POINTER(Plan), _P, _P, _P, _P, C.c_int, C.c_float, C.c_float, _P, _P, _P],
     'msdf_sdf_fwd_grad': [C.POINTER(Plan), C.POINTER(FgArgs), _P],
     'msdf_sdf_backward': [C.POINTER(Plan), C.POINTER(BwArgs), _P],
     'msdf_color_forward': [C.POINTER(Plan), C.POINTER(ColorFwdArgs), _P],

@@ -79,8 +79,10 @@ __global__ void __launch_bounds__(256) msdf_pack_kernel(const msdf_plan_t plan,
 __global__ void __launch_bounds__(MLP_THREADS, 2)
 msdf_sdf_forward_k(const msdf_plan_t plan, const v4f* __restrict__ wpack, const float* __restrict__ bpack,
                    const float* __restrict__ x, const float* __restrict__ aux, const int P,
-                   const float clamp_radius, const float sphere_scale, float* __restrict__ sdf_out) {
+                   const float clamp_radius, const float sphere_scale, float* __restrict__ sdf_out,
+                   const uint32_t* __restrict__ run_flag) {
   extern __shared__ v4f lds[];
+  if (run_flag != nullptr && *run_flag == 0u) return;     // a sampler round nobody asked for (uniform over the grid)
   sdf_forward_body<CoreF32>(plan, wpack, bpack, x, aux, P, clamp_radius, sphere_scale, sdf_out, lds);
 }
 
@@ -100,7 +102,7 @@ msdf_sdf_backward_k(const msdf_plan_t plan, const BwArgs a) {
 int msdf_b16_pack_weights(const msdf_plan_t*, const msdf_packrule_t*, const int*, const float*, const float*, void*,
                           float*, hipStream_t);
 int msdf_b16_sdf_forward(const msdf_plan_t*, const void*, const float*, const float*, const float*, int, float, float,
-                         float*, hipStream_t);
+                         float*, const uint32_t*, hipStream_t);
 int msdf_b16_sdf_fwd_grad(const msdf_plan_t*, const msdf_fg_args_t*, hipStream_t);
 int msdf_b16_sdf_backward(const msdf_plan_t*, const msdf_bw_args_t*, hipStream_t);
 
@@ -119,19 +121,26 @@ extern "C" int msdf_pack_weights(const msdf_plan_t* plan, const msdf_packrule_t*
   return msdf_check_launch();
 }
 
-extern "C" int msdf_sdf_forward(const msdf_plan_t* plan, const void* wpack, const float* bpack, const float* x,
-                                const float* aux, int P, float clamp_radius, float sphere_scale, float* sdf,
-                                void* stream) {
+extern "C" int msdf_sdf_forward_if(const msdf_plan_t* plan, const void* wpack, const float* bpack, const float* x,
+                                   const float* aux, int P, float clamp_radius, float sphere_scale, float* sdf,
+                                   const uint32_t* run_flag, void* stream) {
   if (plan == nullptr || P < 0) return MSDF_ERR_ARG;
   if (P == 0) return MSDF_OK;
   if (plan->aux_tiles > 0 && aux == nullptr) return MSDF_ERR_ARG;
   if (plan->precision == MSDF_PRECISION_BF16X3)
-    return msdf_b16_sdf_forward(plan, wpack, bpack, x, aux, P, clamp_radius, sphere_scale, sdf, (hipStream_t)stream);
+    return msdf_b16_sdf_forward(plan, wpack, bpack, x, aux, P, clamp_radius, sphere_scale, sdf, run_flag,
+                                (hipStream_t)stream);
   if (mlp_prepare((const void*)msdf_sdf_forward_k)) return MSDF_ERR_LAUNCH;
   const int grid = (P + MLP_PTS_PER_WG - 1) / MLP_PTS_PER_WG;
   msdf_sdf_forward_k<<<grid, MLP_THREADS, MLP_LDS_BYTES, (hipStream_t)stream>>>(
-      *plan, (const v4f*)wpack, bpack, x, aux, P, clamp_radius, sphere_scale, sdf);
+      *plan, (const v4f*)wpack, bpack, x, aux, P, clamp_radius, sphere_scale, sdf, run_flag);
   return msdf_check_launch();
+}
+
+extern "C" int msdf_sdf_forward(const msdf_plan_t* plan, const void* wpack, const float* bpack, const float* x,
+                                const float* aux, int P, float clamp_radius, float sphere_scale, float* sdf,
+                                void* stream) {
+  return msdf_sdf_forward_if(plan, wpack, bpack, x, aux, P, clamp_radius, sphere_scale, sdf, nullptr, stream);
 }
 
 extern "C" int msdf_sdf_fwd_grad(const msdf_plan_t* plan, const msdf_fg_args_t* a, void* stream) {

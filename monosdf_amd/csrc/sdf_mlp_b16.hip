@@ -70,8 +70,10 @@ __global__ void __launch_bounds__(256) msdf_pack_b16_kernel(const msdf_plan_t pl
 __global__ void __launch_bounds__(B16_THREADS, 2)
 msdf_sdf_forward_b16_k(const msdf_plan_t plan, const v8bf* __restrict__ wpack, const float* __restrict__ bpack,
                        const float* __restrict__ x, const float* __restrict__ aux, const int P,
-                       const float clamp_radius, const float sphere_scale, float* __restrict__ sdf_out) {
+                       const float clamp_radius, const float sphere_scale, float* __restrict__ sdf_out,
+                       const uint32_t* __restrict__ run_flag) {
   extern __shared__ v8bf lds16[];
+  if (run_flag != nullptr && *run_flag == 0u) return;
   sdf_forward_body<CoreB16>(plan, wpack, bpack, x, aux, P, clamp_radius, sphere_scale, sdf_out, lds16);
 }
 
@@ -101,11 +103,11 @@ int msdf_b16_pack_weights(const msdf_plan_t* plan, const msdf_packrule_t* rules_
 
 int msdf_b16_sdf_forward(const msdf_plan_t* plan, const void* wpack, const float* bpack, const float* x,
                          const float* aux, int P, float clamp_radius, float sphere_scale, float* sdf,
-                         hipStream_t stream) {
+                         const uint32_t* run_flag, hipStream_t stream) {
   if (b16_prepare((const void*)msdf_sdf_forward_b16_k)) return MSDF_ERR_LAUNCH;
   const int grid = (P + B16_PTS_PER_WG - 1) / B16_PTS_PER_WG;
   msdf_sdf_forward_b16_k<<<grid, B16_THREADS, B16_LDS_BYTES, stream>>>(*plan, (const v8bf*)wpack, bpack, x, aux, P,
-                                                                       clamp_radius, sphere_scale, sdf);
+                                                                       clamp_radius, sphere_scale, sdf, run_flag);
   return msdf_check_launch();
 }
 

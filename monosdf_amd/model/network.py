@@ -194,14 +194,14 @@ class _SdfBase(_FusedNet):
         P = x.shape[0]
         return self.evaluate(x, P, P)
 
-    def _sdf_only(self, x):
+    def _sdf_only(self, x, run_flag=None):
         fused, _, _, wpack, bpack = self.packed(x.device)
         aux = None
         if self.aux_active:
             with torch.no_grad():
                 aux = self._pad_aux(self.encoding((x / self.divide_factor).detach(), calc_grad_inputs=False))
         radius = self.sdf_bounding_sphere if self.clamps else 0.0
-        return ops.sdf_forward_nograd(fused, wpack, bpack, x.detach(), aux, radius, self.sphere_scale)
+        return ops.sdf_forward_nograd(fused, wpack, bpack, x.detach(), aux, radius, self.sphere_scale, run_flag)
 
 
 class ImplicitNetwork(_SdfBase):
@@ -351,7 +351,8 @@ class MonoSDFNetwork(nn.Module):
         self.density = LaplaceDensity(**conf.get_config('density'))
         self.ray_sampler = ErrorBoundSampler(self.scene_bounding_sphere, **conf.get_config('ray_sampler'))
         self._noise = None      # tests inject the six random draws here (SURVEY.md 8(a) RNG note)
-        self.speculate_rounds = os.environ.get('MSDF_SPECULATE_ROUNDS', '1') != '0'   # see forward()
+        env = os.environ.get('MSDF_SPECULATE_ROUNDS', '1')          # see forward()
+        self.speculate_rounds = False if env == '0' else ('all' if env == 'all' else True)
 
     def set_precision(self, precision):
         """'fp32' or 'bf16x3' matrix core for the fused MLP kernels (not a reference option)."""
@@ -390,19 +391,26 @@ class MonoSDFNetwork(nn.Module):
         device = ray_dirs.device
         noise = self._noise or {}
         net = self.implicit_network
+        beta = self.density.get_beta()          # once per pass: the sampler and the compositor use the same value
         net.share(device)
         self.rendering_network.share(device)
         try:
             pose = input_dict['ray_pose'] if if_pixel_input else input_dict['pose'][:1]
-            # The sampler reads one batch-global flag per round back to the host, and the GPU would drain while the
-            # host waits and then issues the big kernels.  So the first attempt runs as many rounds as the previous
-            # call needed WITHOUT reading the flags, enqueues everything, and only then looks at them (they have
-            # been on their way since the sampler kernels finished).  Rounds enqueued beyond the ones the flags ask
-            # for return at once on the device, so only a guess that was too SMALL repeats the pass (with the syncs).
-            guess = self.ray_sampler.guess_rounds() if self.speculate_rounds else 0
-            for attempt in (guess, 0):
+            # The sampler's batch-global "another round?" decision (reference ray_sampler.py:179) lives on the device:
+            # every launch of a round that was not asked for returns at once (its SDF evaluation included), so
+            # enqueueing too many rounds costs a few empty launches and changes nothing.  The host therefore
+            # enqueues as many rounds as the most demanding of the last calls needed WITHOUT reading a flag back,
+            # enqueues the rest of the pass, and only then looks at the flags (on their way since the sampler
+            # kernels finished).  Only if the last enqueued round asked for one more is the pass repeated, with
+            # all max_total_iters rounds.  speculate_rounds: True / 'history' (this), 'all' (always all rounds:
+            # no read-back at all), False (MSDF_SPECULATE_ROUNDS=0: the reference's loop, one host sync per round).
+            K = self.ray_sampler.max_total_iters
+            mode = self.speculate_rounds
+            guess = 0 if not mode else (K if mode == 'all' else min(K, self.ray_sampler.guess_rounds()))
+            for attempt in (guess, K if guess else 0):
                 # the sampler's last kernel also writes the sample points and (training) the eikonal points
-                z_vals, z_samples_eik, x_all = self.ray_sampler.sample(ray_dirs, cam_loc, self, speculate=attempt)
+                z_vals, z_samples_eik, x_all = self.ray_sampler.sample(ray_dirs, cam_loc, self, speculate=attempt,
+                                                                      beta0=beta)
                 N, S = z_vals.shape
                 P = N * S
                 points_flat = x_all[:P]
@@ -414,9 +422,9 @@ class MonoSDFNetwork(nn.Module):
                 rgb = rgb_flat.reshape(-1, S, 3)
                 # the compositor also rotates the normal map into the camera frame (R^T, reference 608-616)
                 weights, rgb_values, depth_values, normal_map = ops.CompositeFunction.apply(
-                    z_vals, sdf, rgb_flat, gradients_sdf, self.density.get_beta(), depth_scale, self.white_bkgd,
+                    z_vals, sdf, rgb_flat, gradients_sdf, beta, depth_scale, self.white_bkgd,
                     self._bg_list(), pose)
-                if attempt == 0 or self.ray_sampler.confirm():
+                if attempt == 0 or attempt == K or self.ray_sampler.confirm():
                     break
         finally:
             net.unshare()

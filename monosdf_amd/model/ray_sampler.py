@@ -78,8 +78,8 @@ class ErrorBoundSampler(RaySampler):
         self.max_total_iters = max_total_iters
         self.scene_bounding_sphere = scene_bounding_sphere
         self.add_tiny = add_tiny
-        self.last_rounds = 0
-        self._history = []        # rounds of the last few calls: the next speculative call runs their maximum
+        self._last_rounds = 0
+        self._history = []        # rounds of the last few calls
         self._pending = None
         self._eval_columns = {}
         # speculation bookkeeping (bench.py reports it): calls, passes repeated because too few rounds were
@@ -135,9 +135,20 @@ class ErrorBoundSampler(RaySampler):
             self._eval_columns[key] = torch.stack(rows).to(dev)
         return self._eval_columns[key]
 
-    def confirm(self):
-        """After a speculative sample(): False if the last round that was enqueued asked for another one (the
-        pass has to be repeated with more rounds); otherwise the result is exact, however many were enqueued."""
+    @property
+    def last_rounds(self):
+        """Rounds the last call ran (waits for its flags if they have not been read back yet)."""
+        self._resolve()
+        return self._last_rounds
+
+    @last_rounds.setter
+    def last_rounds(self, value):
+        self._resolve()
+        self._last_rounds = int(value)
+
+    def _resolve(self):
+        """Read the flags of the last speculative call (copied to pinned memory behind the sampler kernels).
+        Returns False if its last enqueued round asked for one more."""
         if self._pending is None:
             return True
         ev, host, k = self._pending
@@ -154,14 +165,22 @@ class ErrorBoundSampler(RaySampler):
         self._note_rounds(ran)
         return True
 
+    def confirm(self):
+        """After a speculative sample(): False if the last round that was enqueued asked for another one (the
+        pass has to be repeated with more rounds); otherwise the result is exact, however many were enqueued.
+        With max_total_iters rounds enqueued that cannot happen, and nothing is read back here."""
+        if self._pending is None or self._pending[2] >= self.max_total_iters:
+            return True
+        return self._resolve()
+
     def _note_rounds(self, rounds):
-        self.last_rounds = rounds
-        self._history = (self._history + [rounds])[-4:]
+        self._last_rounds = rounds
+        self._history = (self._history + [rounds])[-8:]
 
     def guess_rounds(self):
         return max(self._history) if self._history else 1
 
-    def sample(self, ray_dirs, cam_loc, model, want_points=True, speculate=0):
+    def sample(self, ray_dirs, cam_loc, model, want_points=True, speculate=0, beta0=None):
         """get_z_vals plus (optionally) the 3-D points of the ray samples and, in training, the eikonal
         points appended behind them -- written by the finish kernel instead of ~15 small tensor ops.
 
@@ -171,6 +190,7 @@ class ErrorBoundSampler(RaySampler):
         enough."""
         dev = ray_dirs.device
         ray_dirs, cam_loc = _need_gpu(ray_dirs), _need_gpu(cam_loc)
+        self._resolve()               # bookkeeping of the previous call (its flags arrived long ago)
         N = ray_dirs.shape[0]
         n_eval, n_final, n_extra = self.N_samples_eval, self.N_samples, self.N_samples_extra
         K = self.max_total_iters
@@ -179,7 +199,7 @@ class ErrorBoundSampler(RaySampler):
         noise = getattr(model, '_noise', None) or {}
         training = bool(model.training)
         net = model.implicit_network
-        beta0 = model.density.get_beta().detach().float().reshape(1).contiguous()
+        beta0 = (model.density.get_beta() if beta0 is None else beta0).detach().float().reshape(1).contiguous()
         f32 = dict(device=dev, dtype=torch.float32)
         z = torch.empty(N, m_max, **f32)
         sdf = torch.empty(N, m_max, **f32)
@@ -252,7 +272,10 @@ class ErrorBoundSampler(RaySampler):
         rounds = 0
         with torch.no_grad():
             while True:
-                new_sdf = net.get_sdf_vals(pts)                       # fused forward kernel, [N*n_eval, 1]
+                # fused forward kernel on the new points, [N*n_eval, 1]; in a speculated round it returns at once
+                # when the previous round did not ask for this one
+                run_flag = flags.data_ptr() + 4 * (2 * rounds - 1) if (speculate > 0 and rounds > 0) else None
+                new_sdf = net._sdf_only(pts, run_flag=run_flag)
                 a.new_sdf = new_sdf.data_ptr()
                 a.M, a.round_idx = n_eval * (rounds + 1), rounds
                 _lib.call('msdf_sampler_beta', C.byref(a), st)

@@ -44,6 +44,7 @@ _SIDE_STREAMS = {}
 _DEFERRED = []         # launches queued for the side stream: callables
 _PENDING = []          # events of side-stream work whose results the main stream has not waited for yet
 USE_SIDE_STREAM = _os.environ.get('MSDF_SIDE_STREAM', '1') != '0'
+COLOR_WGRAD_EARLY = _os.environ.get('MSDF_COLOR_WGRAD_EARLY', '1') != '0'
 
 
 def _side_stream(device):
@@ -261,14 +262,15 @@ def fused_weight_norm(state, layers):
 # ---------------------------------------------------------------------------
 # SDF network
 # ---------------------------------------------------------------------------
-def sdf_forward_nograd(mlp, wpack, bpack, x, aux, clamp_radius, sphere_scale):
-    """get_sdf_vals: forward only (sampler)."""
+def sdf_forward_nograd(mlp, wpack, bpack, x, aux, clamp_radius, sphere_scale, run_flag=None):
+    """get_sdf_vals: forward only (sampler).  run_flag: device address of a uint32; the launch does nothing when
+    it holds 0 (a sampler round that the previous round did not ask for)."""
     x = _need_cuda(x, 'points')
     P = x.shape[0]
     out = torch.empty(P, 1, device=x.device, dtype=torch.float32)
-    _lib.call('msdf_sdf_forward', C.byref(mlp.plan), _lib.ptr(wpack), _lib.ptr(bpack),
+    _lib.call('msdf_sdf_forward_if', C.byref(mlp.plan), _lib.ptr(wpack), _lib.ptr(bpack),
               _lib.ptr(x), _lib.ptr(aux), P, float(clamp_radius), float(sphere_scale), _lib.ptr(out),
-              _lib.stream_ptr())
+              C.c_void_p(run_flag) if run_flag else None, _lib.stream_ptr())
     return out
 
 
@@ -531,6 +533,10 @@ class ColorMlpFunction(torch.autograd.Function):
         if P > 0:
             _lib.call('msdf_color_backward', C.byref(plan), C.byref(b), _lib.stream_ptr())
             grad = cmlp.run_wgrad(P_pad, {'ws': ws, 'feat': feat}, defer=USE_SIDE_STREAM)
+            if USE_SIDE_STREAM and COLOR_WGRAD_EARLY:
+                # start it now: it then runs beside the SDF backward kernel and fills the partly filled last round
+                # of that kernel's workgroups, instead of starting after it
+                start_side_work(dev)
         else:
             grad = torch.zeros(mp.n_w + mp.n_b, device=dev)
         g_code = None
@@ -778,7 +784,13 @@ class ProbeLossFunction(torch.autograd.Function):
         g1, g2 = _need_cuda(g1.detach(), 'grad_theta'), _need_cuda(g2.detach(), 'grad_theta_nei')
         N, M = rgb.shape[0], g1.shape[0]
         dev = rgb.device
-        outs = [torch.empty_like(t) for t in (rgb, nrm, depth, g1, g2)]
+        # the five gradient tensors are views of one buffer: the backward scales them with ONE multiply
+        sizes = [t.numel() for t in (rgb, nrm, depth, g1, g2)]
+        flat = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
+        outs, off = [], 0
+        for t, n in zip((rgb, nrm, depth, g1, g2), sizes):
+            outs.append(flat[off:off + n].view(t.shape))
+            off += n
         partial = torch.empty((max(N, M) + 255) // 256, device=dev, dtype=torch.float32)
         a = _lib.ProbeLossArgs()
         a.rgb, a.nrm, a.depth, a.g1, a.g2 = [t.data_ptr() for t in (rgb, nrm, depth, g1, g2)]
@@ -787,15 +799,21 @@ class ProbeLossFunction(torch.autograd.Function):
         a.g_rgb, a.g_nrm, a.g_depth, a.g_g1, a.g_g2 = [t.data_ptr() for t in outs]
         a.partial = partial.data_ptr()
         _lib.call('msdf_probe_loss', C.byref(a), _lib.stream_ptr())
-        ctx.save_for_backward(*outs)
-        ctx.depth_shape = None
+        ctx.save_for_backward(flat)
+        ctx.sizes, ctx.shapes = sizes, [t.shape for t in (rgb, nrm, depth, g1, g2)]
         return partial.sum()
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g):
-        g_rgb, g_nrm, g_depth, g_g1, g_g2 = ctx.saved_tensors
-        return (g_rgb * g, g_nrm * g, (g_depth * g).reshape(-1, 1), g_g1 * g, g_g2 * g, None, None, None, None)
+        flat, = ctx.saved_tensors
+        scaled = flat * g
+        res, off = [], 0
+        for n, shape in zip(ctx.sizes, ctx.shapes):
+            res.append(scaled[off:off + n].view(shape))
+            off += n
+        res[2] = res[2].reshape(-1, 1)
+        return tuple(res) + (None, None, None, None)
 
 
 def probe_loss(out, w_normal=0.05, w_depth=0.1, w_eik=0.05, w_smooth=0.005):
@@ -852,9 +870,14 @@ class MonoSdfLossFunction(torch.autograd.Function):
             raise RuntimeError('monosdf_amd: ground-truth tensors do not match the %d rays of the batch' % N)
         out = torch.empty(8, device=dev, dtype=torch.float32)
         mask = torch.empty(N, device=dev, dtype=torch.float32)
-        grads = [torch.empty_like(rgb), torch.empty_like(depth), torch.empty_like(normal)]
-        if has_eik:
-            grads += [torch.empty_like(g1), torch.empty_like(g2)]
+        # the gradient tensors are views of one buffer: the backward scales them with ONE multiply
+        like = [rgb, depth, normal] + ([g1, g2] if has_eik else [])
+        sizes = [t.numel() for t in like]
+        flat = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
+        grads, off = [], 0
+        for t, n in zip(like, sizes):
+            grads.append(flat[off:off + n].view(t.shape))
+            off += n
         a = _lib.MonoSdfLossArgs()
         a.rgb, a.depth, a.normal, a.sdf = rgb.data_ptr(), depth.data_ptr(), normal.data_ptr(), sdf.data_ptr()
         a.grad_theta = g1.data_ptr() if has_eik else None
@@ -869,16 +892,22 @@ class MonoSdfLossFunction(torch.autograd.Function):
         a.g_nei = grads[4].data_ptr() if has_eik else None
         _lib.call('msdf_monosdf_loss', C.byref(a), _lib.stream_ptr())
         ctx.has_eik = has_eik
-        ctx.save_for_backward(*grads)
+        ctx.save_for_backward(flat)
+        ctx.sizes, ctx.shapes = sizes, [t.shape for t in like]
         return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_out):
-        grads = ctx.saved_tensors
-        g = g_out[0]
-        res = [grads[0] * g, (grads[1] * g).reshape(ctx.depth_shape), grads[2] * g]
-        res += [grads[3] * g, grads[4] * g] if ctx.has_eik else [None, None]
+        flat, = ctx.saved_tensors
+        scaled = flat * g_out[0]
+        res, off = [], 0
+        for n, shape in zip(ctx.sizes, ctx.shapes):
+            res.append(scaled[off:off + n].view(shape))
+            off += n
+        res[1] = res[1].reshape(ctx.depth_shape)
+        if not ctx.has_eik:
+            res += [None, None]
         return tuple(res) + (None,) * 8
 
 

@@ -54,11 +54,9 @@ def _worker(rank, world, port, q):
         for mode, spec in (('sync', False), ('speculative', True)):
             m.speculate_rounds = spec
             m.ray_sampler.global_rounds = None
-            m.ray_sampler._history = []
             out = m(mine, idx, if_pixel_input=True)
             rounds[mode + '_alone'] = m.ray_sampler.last_rounds
             m.ray_sampler.global_rounds = True
-            m.ray_sampler._history = [2] if spec else []       # a guess that is too small on purpose
             out = m(mine, idx, if_pixel_input=True)
             rounds[mode + '_global'] = m.ray_sampler.last_rounds
             rows = torch.cat([out['z_vals'], out['rgb_values'], out['depth_values'], out['normal_map']], 1)
