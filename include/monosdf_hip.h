@@ -52,7 +52,10 @@ extern "C" {
 #define MSDF_ABI_VERSION 4
 int msdf_abi_version(void);
 
-/* ---- hash grid (reference: hashencoder/src/hashencoder.h:13-15) ---- */
+/* ---- hash grid (reference: hashencoder/src/hashencoder.h:13-15) ----
+ * calc_grad_inputs: 0 / 1 as in the reference (dy_dx laid out [B, L, 3 C]); 2 = the same with dy_dx level-major
+ * [L, B, 3 C], which every kernel here reads and writes as contiguous rows -- a caller that owns dy_dx end to end
+ * passes 2 to all three calls. */
 int msdf_hash_encode_forward(const float* inputs, const float* embeddings, const int* offsets, float* outputs,
                              uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                              int calc_grad_inputs, float* dy_dx, void* stream);

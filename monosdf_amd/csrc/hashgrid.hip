@@ -90,7 +90,10 @@ hg_forward_kernel(const float* __restrict__ inputs, const float* __restrict__ gr
   if (b >= B) return;
   const uint32_t level = blockIdx.y;
   float* out = outputs + ((size_t)level * B + b) * C;
-  float* dy = dy_dx + (size_t)b * 3 * L * C + (size_t)level * 3 * C;
+  // calc_grad_inputs == 2: dy_dx level-major [L, B, 3 C] (a wave writes 64 x 3 C contiguous floats) instead of the
+  // reference's [B, L, 3 C] (3 C floats every L 3 C: partial lines written by 16 different launches' blocks)
+  float* dy = (calc_grad_inputs == 2) ? dy_dx + ((size_t)level * B + b) * 3 * C
+                                      : dy_dx + (size_t)b * 3 * L * C + (size_t)level * 3 * C;
   const HgCell c = hg_locate(inputs, offsets, b, level, S, H);
   if (c.oob) {
 #pragma unroll
@@ -535,6 +538,23 @@ hb_place_k(const float* __restrict__ grad, const float* __restrict__ grad2, cons
   }
 }
 
+// acc += v in LDS as a compare-and-swap loop.  Measured on MI355X (scripts/dbg/lds_atomics.hip, random addresses in
+// 32 KB, 16 waves per CU): ds_add_f32 costs 170 cycles per wave-instruction whatever the addresses, ds_add_u32 and
+// ds_cmpst 8, this loop 23 (51 with 8 lanes per address) -- the float LDS atomic is the slow one, not LDS atomics.
+__device__ __forceinline__ void lds_add_f32(float* p, const float v) {
+  uint32_t* u = (uint32_t*)p;
+  uint32_t old = *u;
+  while (true) {
+    // the sum goes through an opaque instruction: left visible, the compiler recognises the loop as an atomic float
+    // add and turns it back into ds_add_f32
+    float sum;
+    asm volatile("v_add_f32 %0, %1, %2" : "=v"(sum) : "v"(__uint_as_float(old)), "v"(v));
+    const uint32_t got = atomicCAS(u, old, __float_as_uint(sum));
+    if (got == old) break;
+    old = got;
+  }
+}
+
 template <int C>
 __global__ void __launch_bounds__(HB_THREADS)
 hb_accumulate_k(const int* __restrict__ ws, const HbLayout y, float* __restrict__ grad_grid) {
@@ -567,13 +587,10 @@ hb_accumulate_k(const int* __restrict__ ws, const HbLayout y, float* __restrict_
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (i0 + u * HB_THREADS < r1) {
-        // channel planes: the 64 lanes of one ds_add_f32 spread over all 32 banks.  (Measured, B = 104,448: these
-        // LDS float atomics ARE what bounds this kernel -- 0.133 of its 0.155 ms, ~86 cycles per wave-instruction,
-        // the same with interleaved channels; loads 0.02 ms, flush 0.005 ms: profiles/r02_hash_scatter.md)
+        // channel planes: the 64 lanes of one LDS instruction spread over all 32 banks.  With ds_add_f32 these adds
+        // were 0.133 of the kernel's 0.155 ms at B = 104,448 (profiles/r02_hash_scatter.md)
 #pragma unroll
-        for (int ch = 0; ch < C; ++ch) {
-          atomicAdd(&acc[ch * epb + e[u]], v[u][ch]);
-        }
+        for (int ch = 0; ch < C; ++ch) lds_add_f32(&acc[ch * epb + e[u]], v[u][ch]);
       }
     }
   }
@@ -631,18 +648,18 @@ static int hb_run(const float* grad, const float* grad2, const float* inputs, co
 template <int C>
 __global__ void __launch_bounds__(HG_THREADS)
 hg_backward_input_kernel(const float* __restrict__ grad, const float* __restrict__ dy_dx,
-                         float* __restrict__ grad_inputs, const uint32_t B, const uint32_t L) {
+                         float* __restrict__ grad_inputs, const uint32_t B, const uint32_t L, const int level_major) {
   const uint32_t b = blockIdx.x * HG_THREADS + threadIdx.x;
   if (b >= B) return;
   float r0 = 0.f, r1 = 0.f, r2 = 0.f;
-  const float* dy = dy_dx + (size_t)b * L * 3 * C;
   for (uint32_t l = 0; l < L; ++l) {
+    const float* dy = level_major ? dy_dx + ((size_t)l * B + b) * 3 * C : dy_dx + (size_t)b * L * 3 * C + l * 3 * C;
 #pragma unroll
     for (int ch = 0; ch < C; ++ch) {
       const float g = grad[((size_t)l * B + b) * C + ch];
-      r0 += g * dy[l * 3 * C + 0 * C + ch];
-      r1 += g * dy[l * 3 * C + 1 * C + ch];
-      r2 += g * dy[l * 3 * C + 2 * C + ch];
+      r0 += g * dy[0 * C + ch];
+      r1 += g * dy[1 * C + ch];
+      r2 += g * dy[2 * C + ch];
     }
   }
   grad_inputs[(size_t)b * 3 + 0] = r0;
@@ -654,12 +671,14 @@ hg_backward_input_kernel(const float* __restrict__ grad, const float* __restrict
 template <int C>
 __global__ void __launch_bounds__(HG_THREADS)
 hg_second_backward_grad_kernel(const float* __restrict__ gg_inputs, const float* __restrict__ dy_dx,
-                               float* __restrict__ grad_grad, const uint32_t B, const uint32_t L) {
+                               float* __restrict__ grad_grad, const uint32_t B, const uint32_t L,
+                               const int level_major) {
   const uint32_t b = blockIdx.x * HG_THREADS + threadIdx.x;
   if (b >= B) return;
   const uint32_t level = blockIdx.y;
   const float g0 = gg_inputs[(size_t)b * 3 + 0], g1 = gg_inputs[(size_t)b * 3 + 1], g2 = gg_inputs[(size_t)b * 3 + 2];
-  const float* dy = dy_dx + (size_t)b * L * 3 * C + (size_t)level * 3 * C;
+  const float* dy = level_major ? dy_dx + ((size_t)level * B + b) * 3 * C
+                                : dy_dx + (size_t)b * L * 3 * C + (size_t)level * 3 * C;
 #pragma unroll
   for (int ch = 0; ch < C; ++ch)
     grad_grad[((size_t)level * B + b) * C + ch] = g0 * dy[0 * C + ch] + g1 * dy[1 * C + ch] + g2 * dy[2 * C + ch];
@@ -707,7 +726,7 @@ extern "C" int msdf_hash_encode_backward(const float* grad, const float* inputs,
       if (rc != MSDF_OK) return rc;
     }
     if (calc_grad_inputs)
-      hg_backward_input_kernel<CC><<<grid.x, HG_THREADS, 0, st>>>(grad, dy_dx, grad_inputs, B, L);
+      hg_backward_input_kernel<CC><<<grid.x, HG_THREADS, 0, st>>>(grad, dy_dx, grad_inputs, B, L, calc_grad_inputs == 2);
   });
   return msdf_check_launch();
 }
@@ -732,7 +751,8 @@ extern "C" int msdf_hash_encode_backward_ws(const float* grad, const float* inpu
       if (rc != MSDF_OK) return rc;
     }
     if (calc_grad_inputs)
-      hg_backward_input_kernel<CC><<<(B + HG_THREADS - 1) / HG_THREADS, HG_THREADS, 0, st>>>(grad, dy_dx, grad_inputs, B, L);
+      hg_backward_input_kernel<CC><<<(B + HG_THREADS - 1) / HG_THREADS, HG_THREADS, 0, st>>>(grad, dy_dx, grad_inputs, B, L,
+                                                                                             calc_grad_inputs == 2);
   });
   return msdf_check_launch();
 }
@@ -743,7 +763,7 @@ extern "C" int msdf_hash_encode_second_backward_ws(const float* grad, const floa
                                                    const float* dy_dx, const float* grad_grad_inputs,
                                                    float* grad_grad, float* grad2_embeddings, uint64_t n_entries,
                                                    void* workspace, uint64_t workspace_bytes, void* stream) {
-  (void)embeddings; (void)calc_grad_inputs;
+  (void)embeddings;
   if (D != 3) return MSDF_ERR_UNSUPPORTED;
   if (C == 1) return MSDF_ERR_UNSUPPORTED;
   if (B == 0) return MSDF_OK;
@@ -751,7 +771,8 @@ extern "C" int msdf_hash_encode_second_backward_ws(const float* grad, const floa
   const dim3 grid((B + HG_THREADS - 1) / HG_THREADS, L);
   HG_DISPATCH_C(C, {
     if (grad_grad != nullptr)
-      hg_second_backward_grad_kernel<CC><<<grid, HG_THREADS, 0, st>>>(grad_grad_inputs, dy_dx, grad_grad, B, L);
+      hg_second_backward_grad_kernel<CC><<<grid, HG_THREADS, 0, st>>>(grad_grad_inputs, dy_dx, grad_grad, B, L,
+                                                                    calc_grad_inputs == 2);
     if (grad2_embeddings != nullptr) {
       const int rc = hb_run<CC, 1>(grad, nullptr, inputs, offsets, grad_grad_inputs, grad2_embeddings, B, L, S, H,
                                    n_entries, workspace, workspace_bytes, st);
@@ -787,14 +808,15 @@ extern "C" int msdf_hash_encode_second_backward(const float* grad, const float* 
                                                 float S, uint32_t H, int calc_grad_inputs, const float* dy_dx,
                                                 const float* grad_grad_inputs, float* grad_grad,
                                                 float* grad2_embeddings, void* stream) {
-  (void)embeddings; (void)calc_grad_inputs;
+  (void)embeddings;
   if (D != 3) return MSDF_ERR_UNSUPPORTED;
   if (C == 1) return MSDF_ERR_UNSUPPORTED;   // the reference has no C=1 second backward either (cu:678-684)
   if (B == 0) return MSDF_OK;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((B + HG_THREADS - 1) / HG_THREADS, L);
   HG_DISPATCH_C(C, {
-    hg_second_backward_grad_kernel<CC><<<grid, HG_THREADS, 0, st>>>(grad_grad_inputs, dy_dx, grad_grad, B, L);
+    hg_second_backward_grad_kernel<CC><<<grid, HG_THREADS, 0, st>>>(grad_grad_inputs, dy_dx, grad_grad, B, L,
+                                                                    calc_grad_inputs == 2);
     const int rc = hg_launch_scatter<CC, true>(grad, inputs, offsets, grad_grad_inputs, grad2_embeddings, B, L, S, H, st);
     if (rc != MSDF_OK) return rc;
   });

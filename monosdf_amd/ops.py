@@ -402,7 +402,7 @@ class GridSdfFunction(torch.autograd.Function):
         dy_dx = torch.empty(B, L * D * Cdim, device=x.device, dtype=torch.float32)
         st = _lib.stream_ptr()
         _lib.call('msdf_hash_encode_forward', _lib.ptr(x01), _lib.ptr(emb), _lib.ptr(offsets), _lib.ptr(outputs), B, D,
-                  Cdim, L, S, H, 1, _lib.ptr(dy_dx), st)
+                  Cdim, L, S, H, 2, _lib.ptr(dy_dx), st)
         A = 16 * mlp.plan.aux_tiles
         aux = outputs.permute(1, 0, 2).reshape(B, L * Cdim)
         if A != L * Cdim:
@@ -416,7 +416,7 @@ class GridSdfFunction(torch.autograd.Function):
         r_lbc = r_aux[:, :L * Cdim].reshape(B, L, Cdim).permute(1, 0, 2).contiguous()
         through = torch.empty(B, D, device=x.device, dtype=torch.float32)
         _lib.call('msdf_hash_encode_backward', _lib.ptr(r_lbc), _lib.ptr(x01), _lib.ptr(emb), _lib.ptr(offsets), None,
-                  B, D, Cdim, L, S, H, 1, _lib.ptr(dy_dx), _lib.ptr(through), st)
+                  B, D, Cdim, L, S, H, 2, _lib.ptr(dy_dx), _lib.ptr(through), st)
         k = 0.5 / divide_factor
         ns = inner.n_split
         through = through * k
@@ -446,7 +446,7 @@ class GridSdfFunction(torch.autograd.Function):
         # ... its term for d sdf / d feature: grad_grad[l,b,c] = sum_d gg[b,d] dy_dx[b,l,d,c]
         grad_grad = torch.empty(L, B, Cdim, device=dev, dtype=torch.float32)
         _lib.call('msdf_hash_encode_second_backward_ws', _lib.ptr(r_lbc), _lib.ptr(x01), None, _lib.ptr(ctx.offsets), B, D,
-                  Cdim, L, S, H, 1, _lib.ptr(dy_dx), _lib.ptr(gg), _lib.ptr(grad_grad), None, ctx.n_entries, None, 0, st)
+                  Cdim, L, S, H, 2, _lib.ptr(dy_dx), _lib.ptr(gg), _lib.ptr(grad_grad), None, ctx.n_entries, None, 0, st)
         A = 16 * inner.mlp.plan.aux_tiles
         g_raux = grad_grad.permute(1, 0, 2).reshape(B, L * Cdim)
         if A != L * Cdim:

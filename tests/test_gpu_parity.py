@@ -265,6 +265,17 @@ def test_hash_encoder_kernels():
                   _lib.ptr(fused), B, 3, C, L, geo['S'], geo['H'], _lib.ptr(ggi_g), n_entries, _lib.ptr(ws), nbytes, st)
         want = ge_o + hg.second_backward_embedding(grad2, x, ggi, geo, geo['n_entries'])
         assert rel_err(fused, want) < 1e-5
+        # calc_grad_inputs = 2: dy_dx level-major [L, B, 3 C] in all three entry points, same numbers
+        out_l, dy_l = torch.empty(L, B, C, device='cuda'), torch.empty(L, B, 3 * C, device='cuda')
+        _lib.call('msdf_hash_encode_forward', _lib.ptr(xg), _lib.ptr(eg), _lib.ptr(offs), _lib.ptr(out_l), B, 3, C, L,
+                  geo['S'], geo['H'], 2, _lib.ptr(dy_l), st)
+        assert torch.equal(out_l, out) and torch.equal(dy_l.permute(1, 0, 2).reshape(B, L * 3 * C), dy)
+        gi_l, gg_l = torch.zeros_like(xg), torch.zeros(L, B, C, device='cuda')
+        _lib.call('msdf_hash_encode_backward', _lib.ptr(grad_g), _lib.ptr(xg), _lib.ptr(eg), _lib.ptr(offs), None,
+                  B, 3, C, L, geo['S'], geo['H'], 2, _lib.ptr(dy_l), _lib.ptr(gi_l), st)
+        _lib.call('msdf_hash_encode_second_backward_ws', _lib.ptr(grad_g), _lib.ptr(xg), None, _lib.ptr(offs), B, 3, C, L,
+                  geo['S'], geo['H'], 2, _lib.ptr(dy_l), _lib.ptr(ggi_g), _lib.ptr(gg_l), None, n_entries, None, 0, st)
+        assert torch.equal(gi_l, gi) and torch.equal(gg_l, gg)
         with pytest.raises(RuntimeError):          # a workspace that is too small is refused, not overrun
             _lib.call('msdf_hash_encode_backward_ws', _lib.ptr(grad_g), _lib.ptr(xg), _lib.ptr(eg), _lib.ptr(offs),
                       _lib.ptr(ge_b), B, 3, C, L, geo['S'], geo['H'], 0, _lib.ptr(dy), None, n_entries,
