@@ -538,23 +538,6 @@ hb_place_k(const float* __restrict__ grad, const float* __restrict__ grad2, cons
   }
 }
 
-// acc += v in LDS as a compare-and-swap loop.  Measured on MI355X (scripts/dbg/lds_atomics.hip, random addresses in
-// 32 KB, 16 waves per CU): ds_add_f32 costs 170 cycles per wave-instruction whatever the addresses, ds_add_u32 and
-// ds_cmpst 8, this loop 23 (51 with 8 lanes per address) -- the float LDS atomic is the slow one, not LDS atomics.
-__device__ __forceinline__ void lds_add_f32(float* p, const float v) {
-  uint32_t* u = (uint32_t*)p;
-  uint32_t old = *u;
-  while (true) {
-    // the sum goes through an opaque instruction: left visible, the compiler recognises the loop as an atomic float
-    // add and turns it back into ds_add_f32
-    float sum;
-    asm volatile("v_add_f32 %0, %1, %2" : "=v"(sum) : "v"(__uint_as_float(old)), "v"(v));
-    const uint32_t got = atomicCAS(u, old, __float_as_uint(sum));
-    if (got == old) break;
-    old = got;
-  }
-}
-
 template <int C>
 __global__ void __launch_bounds__(HB_THREADS)
 hb_accumulate_k(const int* __restrict__ ws, const HbLayout y, float* __restrict__ grad_grid) {
@@ -587,10 +570,13 @@ hb_accumulate_k(const int* __restrict__ ws, const HbLayout y, float* __restrict_
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (i0 + u * HB_THREADS < r1) {
-        // channel planes: the 64 lanes of one LDS instruction spread over all 32 banks.  With ds_add_f32 these adds
-        // were 0.133 of the kernel's 0.155 ms at B = 104,448 (profiles/r02_hash_scatter.md)
+        // channel planes: the 64 lanes of one ds_add_f32 spread over all 32 banks.  These LDS float atomics are what
+        // bounds the kernel (0.133 of its 0.155 ms at B = 104,448; loads 0.02, flush 0.005).  ds_add_f32 costs ~170
+        // cycles per wave-instruction on gfx950 against 8 for ds_add_u32 (scripts/dbg/lds_atomics.hip); a
+        // compare-and-swap loop is 7x faster in that microbenchmark but was slower here (0.30 -> 0.38 ms per step:
+        // the ray samples' coarse-level records repeat entries, every repeat is a retry) -- profiles/r02_hash_scatter.md
 #pragma unroll
-        for (int ch = 0; ch < C; ++ch) lds_add_f32(&acc[ch * epb + e[u]], v[u][ch]);
+        for (int ch = 0; ch < C; ++ch) atomicAdd(&acc[ch * epb + e[u]], v[u][ch]);
       }
     }
   }
