@@ -139,15 +139,20 @@ def pmc_traffic(entry, precision):
 
 
 def pmc_traffic_grid(entry):
-    kernels = {'msdf_hash_encode_forward': ['hg_forward_kernel'],
-               'msdf_hash_encode_backward': ['hg_scatter_kernel', 'hg_input_backward_kernel'],
-               'msdf_hash_encode_second_backward': ['hg_scatter_kernel', 'hg_second_grad_kernel']}
+    """HBM bytes per call of a hash entry point = the sum over its kernels (profiles/r02_pmc_grid.json; FETCH_SIZE x2 +
+    WRITE_SIZE; the x2 of MI355X_MICROARCH.md is calibrated for wide streaming reads, not for 8-byte gathers: the
+    forward kernel's figure is an upper bound)."""
+    kernels = {'msdf_hash_encode_forward': ['void hg_forward_kernel'],
+               'msdf_hash_encode_backward': ['void hg_backward_input_kernel'],
+               'msdf_hash_encode_second_backward_ws': ['void hg_second_backward_grad_kernel'],
+               'msdf_hash_encode_backward_fused': ['hb_setup_k', 'void hb_count_k', 'hb_scan_k', 'void hb_place_k',
+                                                   'void hb_accumulate_k']}
     path = os.path.join(ROOT, 'profiles', 'r02_pmc_grid.json')
-    if not os.path.exists(path):
+    if not os.path.exists(path) or entry not in kernels:
         return None, None
     table = json.load(open(path))
     tot = 0.0
-    for k in kernels.get(entry, []):
+    for k in kernels[entry]:
         row = next((v for name, v in table.items() if name.startswith(k)), None)
         if row is None or 'hbm_bytes_per_launch_corrected' not in row:
             return None, None
@@ -223,7 +228,19 @@ def main():
     use_dist = world > 1 or os.environ.get('MSDF_FORCE_DIST') == '1'    # the env knob exercises RCCL on one GPU
     if use_dist:
         import torch.distributed as dist
-        dist.init_process_group(backend='nccl', init_method='env://', device_id=device)
+        # RCCL may print a version banner on stdout when the first communicator is built: keep stdout for the one
+        # JSON line (the banner goes to stderr)
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend='nccl', init_method='env://', device_id=device)
+            dist.barrier(device_ids=[local_rank])
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     from monosdf_amd import _lib, ops, parallel
     from monosdf_amd.model.network import MonoSDFNetwork

@@ -396,7 +396,8 @@ hb_count_k(const float* __restrict__ inputs, const int* __restrict__ offsets, in
 // exclusive scans over the bins: record offsets, and the list of work items for hb_accumulate_k -- one per
 // HB_CHUNK records of a bin: {first record, end record, first float of the slice in the table, floats | shared flag}
 __global__ void __launch_bounds__(1024)
-hb_scan_k(int* __restrict__ ws, const HbLayout y, const int* __restrict__ offsets, const uint32_t L, const uint32_t C) {
+hb_scan_k(int* __restrict__ ws, const HbLayout y, const int* __restrict__ offsets, const uint32_t L, const uint32_t C,
+          const float S, const uint32_t H) {
   __shared__ int part[1024], partw[1024];
   const int nb = ws[0];
   const int t = threadIdx.x;
@@ -433,7 +434,10 @@ hb_scan_k(int* __restrict__ ws, const HbLayout y, const int* __restrict__ offset
       d[0] = run + c * HB_CHUNK;
       d[1] = min(run + n, run + (c + 1) * HB_CHUNK);
       d[2] = (int)(((uint32_t)offsets[level] + e0) * C);   // < 2^31 floats: tables of up to 8 GB
-      d[3] = nf | (chunks > 1 ? (int)0x40000000 : 0);
+      // bit 30: several workgroups share the slice; bit 29: hashed level (its records rarely repeat an entry)
+      const uint64_t res = (uint64_t)ceilf((float)exp2((double)((float)level * S)) * (float)H - 1.0f) + 1u;
+      const bool hashed = res * res * res > (uint64_t)hsize;
+      d[3] = nf | (chunks > 1 ? (int)0x40000000 : 0) | (hashed ? (int)0x20000000 : 0);
     }
     run += n;
     runw += chunks;
@@ -538,6 +542,21 @@ hb_place_k(const float* __restrict__ grad, const float* __restrict__ grad2, cons
   }
 }
 
+// acc += v in LDS as a compare-and-swap loop (for addresses that rarely collide)
+__device__ __forceinline__ void lds_add_cas(float* p, const float v) {
+  uint32_t* u = (uint32_t*)p;
+  uint32_t old = *u;
+  while (true) {
+    // the sum goes through an opaque instruction: left visible, the compiler recognises the loop as an atomic float
+    // add and turns it back into ds_add_f32
+    float sum;
+    asm volatile("v_add_f32 %0, %1, %2" : "=v"(sum) : "v"(__uint_as_float(old)), "v"(v));
+    const uint32_t got = atomicCAS(u, old, __float_as_uint(sum));
+    if (got == old) break;
+    old = got;
+  }
+}
+
 template <int C>
 __global__ void __launch_bounds__(HB_THREADS)
 hb_accumulate_k(const int* __restrict__ ws, const HbLayout y, float* __restrict__ grad_grid) {
@@ -546,8 +565,9 @@ hb_accumulate_k(const int* __restrict__ ws, const HbLayout y, float* __restrict_
   if (w >= ws[1]) return;
   const int4 d = *(const int4*)(ws + y.work + 4 * w);
   const int r0 = d.x, r1 = d.y;
-  const uint32_t nf = (uint32_t)(d.w & 0x3fffffff);
+  const uint32_t nf = (uint32_t)(d.w & 0x1fffffff);
   const bool shared_slice = (d.w & 0x40000000) != 0;
+  const bool hashed = (d.w & 0x20000000) != 0;
   constexpr uint32_t epb = HB_SLICE_FLOATS / C;
   for (uint32_t i = threadIdx.x; i < HB_SLICE_FLOATS; i += HB_THREADS) acc[i] = 0.f;
   __syncthreads();
@@ -573,10 +593,14 @@ hb_accumulate_k(const int* __restrict__ ws, const HbLayout y, float* __restrict_
         // channel planes: the 64 lanes of one ds_add_f32 spread over all 32 banks.  These LDS float atomics are what
         // bounds the kernel (0.133 of its 0.155 ms at B = 104,448; loads 0.02, flush 0.005).  ds_add_f32 costs ~170
         // cycles per wave-instruction on gfx950 against 8 for ds_add_u32 (scripts/dbg/lds_atomics.hip); a
-        // compare-and-swap loop is 7x faster in that microbenchmark but was slower here (0.30 -> 0.38 ms per step:
-        // the ray samples' coarse-level records repeat entries, every repeat is a retry) -- profiles/r02_hash_scatter.md
+        // compare-and-swap loop is 7x faster in that microbenchmark but slower here when used for every level (0.30 ->
+        // 0.38 ms per step: the ray samples' coarse-level records repeat entries, every repeat is a retry), so only
+        // the hashed levels take it -- profiles/r02_hash_scatter.md
 #pragma unroll
-        for (int ch = 0; ch < C; ++ch) atomicAdd(&acc[ch * epb + e[u]], v[u][ch]);
+        for (int ch = 0; ch < C; ++ch) {
+          if (hashed) lds_add_cas(&acc[ch * epb + e[u]], v[u][ch]);
+          else atomicAdd(&acc[ch * epb + e[u]], v[u][ch]);
+        }
       }
     }
   }
@@ -624,7 +648,7 @@ static int hb_run(const float* grad, const float* grad2, const float* inputs, co
   const dim3 grid_pl((B + HB_PTS * HB_THREADS - 1) / (HB_PTS * HB_THREADS), L);
   hb_setup_k<<<1, HB_THREADS, 0, st>>>(ws, y, offsets, L, C);
   hb_count_k<C><<<grid_pl, HB_THREADS, 0, st>>>(inputs, offsets, ws, y, B, S, H);
-  hb_scan_k<<<1, 1024, 0, st>>>(ws, y, offsets, L, C);
+  hb_scan_k<<<1, 1024, 0, st>>>(ws, y, offsets, L, C, S, H);
   hb_place_k<C, MODE><<<grid_pl, HB_THREADS, 0, st>>>(grad, grad2, inputs, offsets, gg_inputs, ws, y, B, S, H);
   hb_accumulate_k<C><<<(unsigned)y.work_max, HB_THREADS, 0, st>>>(ws, y, grad_grid);
   return MSDF_OK;

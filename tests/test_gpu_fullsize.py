@@ -210,3 +210,91 @@ def test_fullsize_binned_scatter_equals_atomic_scatter():
     assert rel(bf, a1 + a2) < 1e-4, rel(bf, a1 + a2)
     # per level: same support (an entry is touched by the binned path exactly when the atomics touch it)
     assert torch.equal(b1 != 0, a1 != 0)
+
+
+def _record(name, payload):
+    """Times of the full-size runs go to gpurun_out/r02_fullsize.json (copied to profiles/ by hand)."""
+    import json
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', 'r02_fullsize.json')
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        data = json.load(open(path)) if os.path.exists(path) else {}
+        data[name] = payload
+        json.dump(data, open(path, 'w'), indent=1)
+    except OSError:
+        pass
+
+
+def test_fullsize_image_render_384():
+    """BASELINE.json configs[3] at full size on one GPU: 384 x 384 pixels in 144 chunks of 1,024 rays (image mode:
+    uv + pose + intrinsics), 8x256 network.  Property: the chunked image equals the same pixels rendered in chunks of
+    another size (rays are independent; at the random-init state every chunk's sampler converges in one round)."""
+    import time
+    from monosdf_amd.utils import render
+    model = _model('fp32').eval()
+    side = 384
+    ys, xs = torch.meshgrid(torch.arange(side), torch.arange(side), indexing='ij')
+    uv = torch.stack([xs.flatten(), ys.flatten()], -1)[None].float().cuda() + 0.5
+    intr = torch.eye(4)[None].clone()
+    intr[0, 0, 0] = intr[0, 1, 1] = 300.0
+    intr[0, 0, 2] = intr[0, 1, 2] = side / 2
+    pose = torch.eye(4)[None].clone()
+    pose[0, :3, 3] = torch.tensor([0.05, -0.1, 0.15])
+    inputs = {'uv': uv, 'pose': pose.cuda(), 'intrinsics': intr.cuda()}
+    idx = torch.zeros(1, dtype=torch.long, device='cuda')
+    total = side * side
+    render.render_image(model, {**inputs, 'uv': uv[:, :2048]}, idx, 2048, split_n_pixels=1024)     # warm-up
+    torch.cuda.synchronize()
+    t0 = time.time()
+    img = render.render_image(model, inputs, idx, total, split_n_pixels=1024)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    assert img['rgb_values'].shape == (total, 3) and img['depth_values'].shape == (total, 1)
+    assert torch.isfinite(img['rgb_values']).all() and (img['rgb_values'] >= 0).all() and (img['rgb_values'] <= 1).all()
+    # a pixel subsample rendered on its own, in chunks of 500: same values
+    g = torch.Generator().manual_seed(0)
+    pick = torch.randperm(total, generator=g)[:3000].cuda()
+    sub = render.render_image(model, {**inputs, 'uv': uv[:, pick]}, idx, pick.numel(), split_n_pixels=500)
+    for k in sub:
+        assert (sub[k] - img[k][pick]).abs().max().item() <= 1e-5 * max(1.0, img[k].abs().max().item()), k
+    _record('configs[3] 384x384 render, 144 chunks of 1024 rays, one GPU, eval mode',
+            {'seconds': dt, 'rays_per_second': total / dt, 'sampler_rounds_last_chunk': model.ray_sampler.last_rounds})
+
+
+def test_fullsize_sdf_volume_512():
+    """BASELINE.json configs[4] at full size on one GPU: the 512^3 coarse-to-fine SDF volume (one block, pyramid
+    64^3 -> 512^3).  Properties: every voxel the pyramid refined to the finest level holds the network's value at its
+    own centre; every other voxel holds the value of the coarser voxel that covers it."""
+    import time
+    import numpy as np
+    from monosdf_amd.utils import render
+    model = _model('fp32').eval()
+    fn = lambda p: model.implicit_network(p)[:, 0]
+    with torch.no_grad():
+        fn(torch.zeros(64, 3, device='cuda'))
+        torch.cuda.synchronize()
+        t0 = time.time()
+        blocks = list(render.sdf_volume(fn, resolution=512, grid_boundary=(-1.1, 1.1), shard=False))
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+    assert len(blocks) == 1
+    origin, spacing, vol = blocks[0]
+    assert vol.shape == (512, 512, 512) and np.isfinite(vol).all()
+    n = 512
+    thr_fine = 2 * 2.2 / n * 8 / 8                       # threshold of the last refinement (plots.py:163,190)
+    near = np.abs(vol) < thr_fine / 2                    # well inside it: certainly refined at every level
+    frac = float(near.mean())
+    assert 0 < frac < 0.2
+    ii = np.argwhere(near)
+    ii = ii[np.random.default_rng(0).permutation(len(ii))[:100000]]
+    axis = np.linspace(-1.1, 1.1, n)
+    pts = torch.from_numpy(np.stack([axis[ii[:, 0]], axis[ii[:, 1]], axis[ii[:, 2]]], 1)).float().cuda()
+    with torch.no_grad():
+        dense = fn(pts).cpu().numpy()
+    got = vol[ii[:, 0], ii[:, 1], ii[:, 2]]
+    assert np.abs(got - dense).max() <= 1e-5, np.abs(got - dense).max()
+    # far from the surface the coarse value is replicated: 8x8x8 blocks of one value
+    far_block = vol[:8, :8, :8]
+    assert np.all(far_block == far_block[0, 0, 0])
+    _record('configs[4] 512^3 SDF volume, coarse-to-fine, one GPU',
+            {'seconds': dt, 'voxels': n ** 3, 'fraction_refined_to_finest_level': frac})
