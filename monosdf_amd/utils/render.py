@@ -41,6 +41,12 @@ def merge_output(res, total_pixels, batch_size):
     return out
 
 
+def lin2img(tensor, img_res):
+    """[B, H*W, C] -> [B, C, H, W] (utils/plots.py:599-601)."""
+    batch_size, num_samples, channels = tensor.shape
+    return tensor.permute(0, 2, 1).view(batch_size, channels, img_res[0], img_res[1])
+
+
 _WIDTH = {'rgb_values': 3, 'normal_map': 3, 'depth_values': 1}
 
 
