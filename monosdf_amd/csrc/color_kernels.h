@@ -152,13 +152,17 @@ __device__ __forceinline__ void color_backward_body(const msdf_plan_t& plan, con
     const float* Hl = a.H + (size_t)L.hpre * Pp + (size_t)pt * (16 * L.kt) + 4 * q;
     const msdf_layer_t Lp = plan.layer[(u - 1 == 1) ? 0 : u - 1];
     float* ABl = a.AB + (size_t)Lp.abpre * Pp + (size_t)pt * (16 * Lp.ot) + 4 * q;
+    // every H load before the first AB store, tile index clamped instead of guarded (sdf_kernels.h, sweep up)
+    const int ktl = L.kt - 1;
+    v4f hh[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) hh[t] = *(const v4f*)(Hl + 16 * (t < ktl ? t : ktl));
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
       v4f ab = V4ZERO;
-      if (t < L.kt) {
-        const v4f h = *(const v4f*)(Hl + 16 * t);
+      if (t == 0 || t < L.kt) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ab[r] = (h[r] > 0.f) ? acc[t][r] : 0.f;
+        for (int r = 0; r < 4; ++r) ab[r] = (hh[t][r] > 0.f) ? acc[t][r] : 0.f;
         *(v4f*)(ABl + 16 * t) = ab;
       }
       in[t] = ab;

@@ -182,13 +182,18 @@ __device__ __forceinline__ void sdf_fwd_grad_body(const msdf_plan_t& plan, const
     const msdf_layer_t L = plan.layer[l];
     const float* Hl = a.H + (size_t)L.hpre * Pp + (size_t)c.pt * (16 * L.ot) + 4 * c.q;
     float* Pl = a.PM + (size_t)L.hpre * Pp + (size_t)c.pt * (16 * L.ot) + 4 * c.q;
+    // every H load before the first PM store (tile index clamped, not guarded): one exposed latency per
+    // layer instead of one load -> wait -> store round trip per tile
+    const int otl = L.ot - 1;
+    v4f hh[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) hh[t] = *(const v4f*)(Hl + 16 * (t < otl ? t : otl));
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
       v4f p = V4ZERO;
-      if (t < L.ot) {
-        const v4f h = *(const v4f*)(Hl + 16 * t);
+      if (t == 0 || t < L.ot) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) p[r] = (1.0f - one_minus_sigmoid_from_h(h[r])) * acc[t][r];
+        for (int r = 0; r < 4; ++r) p[r] = (1.0f - one_minus_sigmoid_from_h(hh[t][r])) * acc[t][r];
         if (a.save) *(v4f*)(Pl + 16 * t) = p;
       }
       in[t] = p;
@@ -309,28 +314,32 @@ __device__ __forceinline__ void sdf_backward_body(const msdf_plan_t& plan, const
       if (t < L.kt) *(v4f*)(Ql + 16 * t) = in[t];
     zero_tiles(acc);
     const size_t off = (size_t)L.hpre * Pp + (size_t)c.pt * (16 * L.ot) + 4 * c.q;
-    // the epilogue's H tiles are fetched while the last weight chunk multiplies (one exposed HBM latency
-    // per layer instead of two)
-    v4f hpre[B_PREFETCH_TILES];
+    // The epilogue's H tiles are fetched while the last weight chunk multiplies; every other load of the
+    // epilogue (tile index clamped instead of guarded, so that no branch separates them) is issued before
+    // its first store.  Guarded loads next to the T stores had become one load -> wait -> store round trip
+    // per tile: 16 exposed memory latencies per product.
+    const int otl = L.ot - 1;
+    v4f hh[MT], pp[MT];
     Core::gemm(L.ktp, acc, in, L.ot, (const wvec*)a.wpack + L.wf_off, lds, NoEpilogue(), [&]() {
 #pragma unroll
-      for (int t = 0; t < B_PREFETCH_TILES; ++t)
-        if (t < L.ot) hpre[t] = *(const v4f*)(a.H + off + 16 * t);
+      for (int t = 0; t < B_PREFETCH_TILES; ++t) hh[t] = *(const v4f*)(a.H + off + 16 * (t < otl ? t : otl));
     });
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
+      const int tc = t < otl ? t : otl;
+      if (!(Core::kTailPrefetch && t < B_PREFETCH_TILES)) hh[t] = *(const v4f*)(a.H + off + 16 * tc);
+      pp[t] = *(const v4f*)(a.PM + off + 16 * tc);
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
       v4f qn = V4ZERO;
-      if (t < L.ot) {
-        v4f h;
-        if (Core::kTailPrefetch && t < B_PREFETCH_TILES) h = hpre[t < B_PREFETCH_TILES ? t : 0];
-        else h = *(const v4f*)(a.H + off + 16 * t);
-        const v4f p = *(const v4f*)(a.PM + off + 16 * t);
+      if (t == 0 || t < L.ot) {   // tile 0 unguarded: its loads stay in the block of the others
         v4f tt;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float u = one_minus_sigmoid_from_h(h[r]);
+          const float u = one_minus_sigmoid_from_h(hh[t][r]);
           const float pb = acc[t][r];
-          tt[r] = 100.0f * u * p[r] * pb;   // s-bar * softplus''  with  p = s q
+          tt[r] = 100.0f * u * pp[t][r] * pb;   // s-bar * softplus''  with  p = s q
           qn[r] = (1.0f - u) * pb;
         }
         *(v4f*)(a.T + off + 16 * t) = tt;
@@ -372,7 +381,7 @@ __device__ __forceinline__ void sdf_backward_body(const msdf_plan_t& plan, const
     const float* src = a.H + (size_t)Ln.hpre * Pp + (size_t)c.pt * (16 * Ln.ot) + 4 * c.q;
 #pragma unroll
     for (int t = 0; t < B_PREFETCH_TILES; ++t)
-      if (t < Ln.ot) hnext[t] = *(const v4f*)(src + 16 * t);
+      hnext[t] = *(const v4f*)(src + 16 * (t < Ln.ot - 1 ? t : Ln.ot - 1));
   };
   Core::gemm(LL.otp, acc, in, LL.kt, (const wvec*)a.wpack + LL.wb_off, lds, NoEpilogue(), [&]() {
     if (nl >= 2) fetch_h(nl - 2);
@@ -384,16 +393,22 @@ __device__ __forceinline__ void sdf_backward_body(const msdf_plan_t& plan, const
     const msdf_layer_t L = plan.layer[l];
     const size_t off = (size_t)L.hpre * Pp + (size_t)c.pt * (16 * L.ot) + 4 * c.q;
     float* ABl = a.AB + (size_t)L.abpre * Pp + (size_t)c.pt * (16 * L.ot) + 4 * c.q;
+    // all loads of the epilogue before its first store, clamped not guarded (see the sweep up)
+    const int otl = L.ot - 1;
+    v4f hh[MT], tt[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int tc = t < otl ? t : otl;
+      if (Core::kTailPrefetch && t < B_PREFETCH_TILES) hh[t] = hnext[t < B_PREFETCH_TILES ? t : 0];
+      else hh[t] = *(const v4f*)(a.H + off + 16 * tc);
+      tt[t] = *(const v4f*)(a.T + off + 16 * tc);
+    }
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
       v4f ab = V4ZERO;
-      if (t < L.ot) {
-        v4f h;
-        if (Core::kTailPrefetch && t < B_PREFETCH_TILES) h = hnext[t < B_PREFETCH_TILES ? t : 0];
-        else h = *(const v4f*)(a.H + off + 16 * t);
-        const v4f tt = *(const v4f*)(a.T + off + 16 * t);
+      if (t == 0 || t < L.ot) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ab[r] = acc[t][r] * (1.0f - one_minus_sigmoid_from_h(h[r])) + tt[r];
+        for (int r = 0; r < 4; ++r) ab[r] = acc[t][r] * (1.0f - one_minus_sigmoid_from_h(hh[t][r])) + tt[t][r];
         *(v4f*)(ABl + 16 * t) = ab;
       }
       in[t] = ab;
