@@ -73,7 +73,7 @@ __device__ __forceinline__ void color_forward_body(const msdf_plan_t& plan, cons
   for (int t = 0; t < MT; ++t)
     in[t] = (t < U0.kt) ? *(const v4f*)(a.feat + (size_t)ptc * (16 * U0.kt) + 16 * t + 4 * q) : V4ZERO;
   load_bias_c(acc, a.bpack + U0.bias_off, U0.ot, q);
-  Core::gemm(U0.ktp, acc, in, U0.ot, (const wvec*)a.wpack + U0.wf_off, lds, NoEpilogue());
+  Core::gemm(U0.ktp, acc, in, U0.ot, (const wvec*)a.wpack + U0.wf_off, lds, NoHooks());
   // ---- first layer, misc part (same accumulators)
   {
     v4f m[5];
@@ -86,7 +86,7 @@ __device__ __forceinline__ void color_forward_body(const msdf_plan_t& plan, cons
     }
   }
   const msdf_layer_t U1 = plan.layer[1];
-  Core::gemm(U1.ktp, acc, in, U1.ot, (const wvec*)a.wpack + U1.wf_off, lds, NoEpilogue());
+  Core::gemm(U1.ktp, acc, in, U1.ot, (const wvec*)a.wpack + U1.wf_off, lds, NoHooks());
   // ---- hidden layers
   for (int u = 2; u < nu; ++u) {
     const msdf_layer_t L = plan.layer[u];
@@ -102,7 +102,7 @@ __device__ __forceinline__ void color_forward_body(const msdf_plan_t& plan, cons
       in[t] = h;
     }
     load_bias_c(acc, a.bpack + L.bias_off, L.ot, q);
-    Core::gemm(L.ktp, acc, in, L.ot, (const wvec*)a.wpack + L.wf_off, lds, NoEpilogue());
+    Core::gemm(L.ktp, acc, in, L.ot, (const wvec*)a.wpack + L.wf_off, lds, NoHooks());
   }
   // ---- output activation: slots 0..2 sit in tile 0, quarter 0
   if (valid && q == 0) {
@@ -147,7 +147,7 @@ __device__ __forceinline__ void color_backward_body(const msdf_plan_t& plan, con
   for (int u = nu - 1; u >= 2; --u) {
     const msdf_layer_t L = plan.layer[u];
     zero_tiles(acc);
-    Core::gemm(L.otp, acc, in, L.kt, (const wvec*)a.wpack + L.wb_off, lds, NoEpilogue());
+    Core::gemm(L.otp, acc, in, L.kt, (const wvec*)a.wpack + L.wb_off, lds, NoHooks());
     // acc = h-bar of this layer's input = output of unit u-1 (u-1 == 1 means the first layer)
     const float* Hl = a.H + (size_t)L.hpre * Pp + (size_t)pt * (16 * L.kt) + 4 * q;
     const msdf_layer_t Lp = plan.layer[(u - 1 == 1) ? 0 : u - 1];
@@ -171,7 +171,7 @@ __device__ __forceinline__ void color_backward_body(const msdf_plan_t& plan, con
   // ---- first layer: gradient of the feature tiles and of the misc block
   const msdf_layer_t U0 = plan.layer[0];
   zero_tiles(acc);
-  Core::gemm(U0.otp, acc, in, U0.kt, (const wvec*)a.wpack + U0.wb_off, lds, NoEpilogue());
+  Core::gemm(U0.otp, acc, in, U0.kt, (const wvec*)a.wpack + U0.wb_off, lds, NoHooks());
   if (valid) {
 #pragma unroll
     for (int t = 0; t < MT; ++t)
@@ -179,7 +179,7 @@ __device__ __forceinline__ void color_backward_body(const msdf_plan_t& plan, con
   }
   const msdf_layer_t U1 = plan.layer[1];
   zero_tiles(acc);
-  Core::gemm(U1.otp, acc, in, U1.kt, (const wvec*)a.wpack + U1.wb_off, lds, NoEpilogue());
+  Core::gemm(U1.otp, acc, in, U1.kt, (const wvec*)a.wpack + U1.wb_off, lds, NoHooks());
   if (valid) {
 #pragma unroll
     for (int t = 0; t < 5; ++t)

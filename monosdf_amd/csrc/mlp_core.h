@@ -57,24 +57,33 @@ __device__ __forceinline__ void chunk_issue(const v4f* __restrict__ src, v4f* ds
 // All 256 threads of the workgroup must call this together (it contains barriers).
 // `lds` points at 2 * LDS_BUF_F4 float4; on return every wave has passed a barrier
 // after its last LDS read, so the caller may start the next gemm immediately.
-struct NoTail {
-  __device__ __forceinline__ void operator()() const {}
+// Hooks of a product: the epilogue of the out tiles is spread over the product instead of forming a phase of
+// its own after it.  Out tiles are finished two at a time (one weight chunk); for every chunk gemm_tiles calls
+//   hk.pre(o0, o1)                 right after the barrier that opens the chunk and the LDS-DMA of the next
+//                                  one: the place to ISSUE memory operations -- the stores a previous post()
+//                                  left pending and the loads post() of THIS chunk will need.  Everything
+//                                  issued here completes under the chunk's 128 MFMAs (>= 2 us), i.e. before
+//                                  the s_waitcnt vmcnt(0) of the next barrier instead of in front of it;
+//   hk.post(o0, o1, pair, a0, a1)  after the chunk's last MFMA: a0 = acc[o0], a1 = acc[o1] are complete
+//                                  (a1 only if `pair`); transform them in place, keep what has to be stored;
+// and the caller runs hk.drain() after the product for the stores of the last chunk.  o0 / o1 are compile-time
+// constants at every call (the chunk loop is unrolled), everything else is wave-uniform.
+struct NoHooks {
+  __device__ __forceinline__ void pre(const int, const int) {}
+  __device__ __forceinline__ void post(const int, const int, const bool, v4f&, v4f&) {}
+  __device__ __forceinline__ void drain() {}
 };
 
-// tail(): called once, after the LAST weight chunk has been waited for and before its matrix products -- the
-// place to issue global loads the caller's epilogue will need: no later s_waitcnt vmcnt inside the GEMM waits
-// for them, and the chunk's ~2 us of MFMAs cover their latency.
-template <int KT_T, class Tail>
+template <int KT_T, class Hooks>
 __device__ __forceinline__ void gemm_tiles(v4f (&acc)[MT], const v4f (&in)[MT], const int OT, const int k_rt,
-                                           const v4f* __restrict__ wsrc, v4f* lds, const Tail& tail) {
+                                           const v4f* __restrict__ wsrc, v4f* lds, Hooks& hk) {
   constexpr bool DYN = (KT_T == 0);
   constexpr int KMAX = DYN ? MT : KT_T;
   const int K = DYN ? k_rt : KT_T;
   const int ch_f4 = CHUNK_OT * K * 64;
   const int lane = threadIdx.x & 63;
   const int nchunks = (OT + CHUNK_OT - 1) / CHUNK_OT;
-  // Chunks are consumed from the LAST pair of out tiles down to the first, so that the final chunk is always
-  // c == 0 -- a compile-time position for the tail hook (its loads are then live in that iteration only).
+  // Chunks are consumed from the LAST pair of out tiles down to the first.
   chunk_issue<CHUNK_OT * KMAX>(wsrc + (size_t)(nchunks - 1) * ch_f4, lds + ((nchunks - 1) & 1) * LDS_BUF_F4, ch_f4);
   __syncthreads();
 #pragma unroll
@@ -84,7 +93,7 @@ __device__ __forceinline__ void gemm_tiles(v4f (&acc)[MT], const v4f (&in)[MT], 
       const bool has_next = (c > 0);
       if (has_next)
         chunk_issue<CHUNK_OT * KMAX>(wsrc + (size_t)(c - 1) * ch_f4, lds + (buf ^ 1) * LDS_BUF_F4, ch_f4);
-      if (c == 0) tail();
+      hk.pre(2 * c, 2 * c + 1);
       const v4f* w0 = lds + buf * LDS_BUF_F4 + lane;
       const v4f* w1 = w0 + K * 64;
       const int o0 = 2 * c;
@@ -157,6 +166,7 @@ __device__ __forceinline__ void gemm_tiles(v4f (&acc)[MT], const v4f (&in)[MT], 
           }
         }
       }
+      hk.post(o0, 2 * c + 1, 2 * c + 1 < MT && 2 * c + 1 < OT, acc[o0], acc[o1]);
       __syncthreads();
     }
   }
@@ -164,16 +174,17 @@ __device__ __forceinline__ void gemm_tiles(v4f (&acc)[MT], const v4f (&in)[MT], 
 
 // Specialised for the K values of the 256-wide networks (3 = PE, 5 = PE + hash-grid features, 16, 17 = skip
 // layer); anything else takes the guarded path.
-template <class Tail>
+template <class Hooks>
 __device__ __forceinline__ void gemm_dispatch(const int kp, v4f (&acc)[MT], const v4f (&in)[MT], const int OT,
-                                              const v4f* __restrict__ wsrc, v4f* lds, const Tail& tail) {
+                                              const v4f* __restrict__ wsrc, v4f* lds, Hooks& hk) {
   switch (kp) {
-    case 3: gemm_tiles<3>(acc, in, OT, 3, wsrc, lds, tail); break;
-    case 5: gemm_tiles<5>(acc, in, OT, 5, wsrc, lds, tail); break;      // PE + hash-grid features
-    case 16: gemm_tiles<16>(acc, in, OT, 16, wsrc, lds, tail); break;
-    case 17: gemm_tiles<17>(acc, in, OT, 17, wsrc, lds, tail); break;
-    default: gemm_tiles<0>(acc, in, OT, kp, wsrc, lds, tail); break;
+    case 3: gemm_tiles<3>(acc, in, OT, 3, wsrc, lds, hk); break;
+    case 5: gemm_tiles<5>(acc, in, OT, 5, wsrc, lds, hk); break;      // PE + hash-grid features
+    case 16: gemm_tiles<16>(acc, in, OT, 16, wsrc, lds, hk); break;
+    case 17: gemm_tiles<17>(acc, in, OT, 17, wsrc, lds, hk); break;
+    default: gemm_tiles<0>(acc, in, OT, kp, wsrc, lds, hk); break;
   }
+  hk.drain();
 }
 
 __device__ __forceinline__ void zero_tiles(v4f (&a)[MT]) {
@@ -291,27 +302,18 @@ __device__ __forceinline__ void pe_jacobian(v4f (&rbar)[5], const float x0, cons
 
 // ---------------------------------------------------------------------------
 // The matrix core as the kernel bodies see it (sdf_kernels.h / color_kernels.h are templated on this).
-// gemm(): acc[0..OT) += W * in, then epi(t, acc[t]) for every produced tile.
+// gemm(): acc[0..OT) += W * in with the product's hooks (see NoHooks) called per pair of out tiles.
 // ---------------------------------------------------------------------------
-struct NoEpilogue {
-  __device__ __forceinline__ void operator()(const int, v4f&) const {}
-};
-
 struct CoreF32 {
   typedef v4f wvec;                                  // one 16-byte element of the weight pack
-  static constexpr bool kTailPrefetch = true;        // gemm() honours the tail hook (see gemm_tiles)
   static __device__ __forceinline__ float softplus(const float a) {
     float h, s;
     softplus100(a, h, s);
     return h;
   }
-  template <class Epi, class Tail = NoTail>
+  template <class Hooks>
   static __device__ __forceinline__ void gemm(const int kp, v4f (&acc)[MT], const v4f (&in)[MT], const int OT,
-                                              const wvec* __restrict__ wsrc, void* lds, const Epi& epi,
-                                              const Tail& tail = Tail()) {
-    gemm_dispatch(kp, acc, in, OT, wsrc, (v4f*)lds, tail);
-#pragma unroll
-    for (int t = 0; t < MT; ++t)
-      if (t < OT) epi(t, acc[t]);
+                                              const wvec* __restrict__ wsrc, void* lds, Hooks&& hk) {
+    gemm_dispatch(kp, acc, in, OT, wsrc, (v4f*)lds, hk);
   }
 };

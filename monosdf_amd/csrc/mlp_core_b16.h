@@ -107,12 +107,13 @@ __device__ __forceinline__ v4f b16_tile_dyn(v4f c, const v8bf* __restrict__ w, c
 }
 
 // acc[0..OT) += W * act;  W = bf16 hi/lo pack [ceil4(OT)][KB][2][64] v8bf;  KB_T > 0: compile-time K-block count.
-// epi(t, acc[t]) runs as soon as out tile t is complete, i.e. between the matrix products of neighbouring
-// tiles: the activation's VALU work overlaps the other wave's MFMAs instead of forming a phase of its own.
+// The product's hooks (mlp_core.h, NoHooks) are called per chunk of two out tiles: pre() after the barrier that
+// opens the chunk, post() after its last MFMA -- the activation's VALU work and the epilogue's memory traffic
+// overlap the other wave's MFMAs instead of forming a phase of their own.
 // All B16_THREADS threads of the workgroup call this together (barriers inside).
-template <int KB_T, class Epi>
+template <int KB_T, class Hooks>
 __device__ __forceinline__ void gemm_b16(v4f (&acc)[MT], const B16Act& act, const int OT, const int kb_rt,
-                                         const v8bf* __restrict__ wsrc, v8bf* lds, const Epi& epi) {
+                                         const v8bf* __restrict__ wsrc, v8bf* lds, Hooks& hk) {
   constexpr bool DYN = (KB_T == 0);
   constexpr int KMAX = DYN ? KB_MAX : KB_T;
   const int KB = DYN ? kb_rt : KB_T;
@@ -127,6 +128,8 @@ __device__ __forceinline__ void gemm_b16(v4f (&acc)[MT], const B16Act& act, cons
       const int buf = c & 1;
       if (c + 1 < nchunks)
         b16_chunk_issue<B16_CHUNK_OT * KMAX * 2>(wsrc + (size_t)(c + 1) * ch_v8, lds + (buf ^ 1) * B16_BUF_V8, ch_v8);
+      static_assert(B16_CHUNK_OT == 2, "the hooks take pairs of out tiles");
+      hk.pre(2 * c, 2 * c + 1);
       const v8bf* w = lds + buf * B16_BUF_V8 + lane;      // [ot in chunk][kb][hi|lo][64]
       // LDS base of this chunk as an opaque 32-bit register: every fragment read below then carries its
       // offset in the instruction's 16-bit immediate instead of a v_add per read (VALU issue slots are
@@ -142,7 +145,6 @@ __device__ __forceinline__ void gemm_b16(v4f (&acc)[MT], const B16Act& act, cons
           if (ot < MT && ot < OT) {
             const int oi = (ot < MT) ? ot : 0;
             acc[oi] = b16_tile_dyn(acc[oi], w + o * KB * 128, act, KB);
-            epi(oi, acc[oi]);
           }
         }
       } else {
@@ -170,40 +172,39 @@ __device__ __forceinline__ void gemm_b16(v4f (&acc)[MT], const B16Act& act, cons
               cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[i % 3], act.lo[kb], cc, 0, 0, 0);
               cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl[i % 3], act.hi[kb], cc, 0, 0, 0);
             }
-            epi(oi, cc);
             acc[oi] = cc;
           }
         }
       }
 #undef B16_FRAG
+      hk.post(2 * c, 2 * c + 1, 2 * c + 1 < MT && 2 * c + 1 < OT, acc[2 * c], acc[(2 * c + 1 < MT) ? 2 * c + 1 : 0]);
       __syncthreads();
     }
   }
 }
 
-template <class Epi>
+template <class Hooks>
 __device__ __forceinline__ void gemm_b16_dispatch(const int kbp, v4f (&acc)[MT], const B16Act& act, const int OT,
-                                                  const v8bf* __restrict__ wsrc, v8bf* lds, const Epi& epi) {
+                                                  const v8bf* __restrict__ wsrc, v8bf* lds, Hooks& hk) {
   switch (kbp) {
-    case 2: gemm_b16<2>(acc, act, OT, 2, wsrc, lds, epi); break;     // PE (3 tiles)
-    case 3: gemm_b16<3>(acc, act, OT, 3, wsrc, lds, epi); break;     // PE + hash-grid features (5 tiles)
-    case 8: gemm_b16<8>(acc, act, OT, 8, wsrc, lds, epi); break;
-    case 9: gemm_b16<9>(acc, act, OT, 9, wsrc, lds, epi); break;
-    default: gemm_b16<0>(acc, act, OT, kbp, wsrc, lds, epi); break;
+    case 2: gemm_b16<2>(acc, act, OT, 2, wsrc, lds, hk); break;     // PE (3 tiles)
+    case 3: gemm_b16<3>(acc, act, OT, 3, wsrc, lds, hk); break;     // PE + hash-grid features (5 tiles)
+    case 8: gemm_b16<8>(acc, act, OT, 8, wsrc, lds, hk); break;
+    case 9: gemm_b16<9>(acc, act, OT, 9, wsrc, lds, hk); break;
+    default: gemm_b16<0>(acc, act, OT, kbp, wsrc, lds, hk); break;
   }
+  hk.drain();
 }
 
 struct CoreB16 {
   typedef v8bf wvec;
-  static constexpr bool kTailPrefetch = false;       // no spare registers: the tail hook is ignored
   static __device__ __forceinline__ float softplus(const float a) { return softplus100_lean(a); }
   // kbp: K blocks (32 slots) of the pack, i.e. ktp / otp of the bf16 plan
-  template <class Epi, class Tail = NoTail>
+  template <class Hooks>
   static __device__ __forceinline__ void gemm(const int kbp, v4f (&acc)[MT], const v4f (&in)[MT], const int OT,
-                                              const wvec* __restrict__ wsrc, void* lds, const Epi& epi,
-                                              const Tail& = Tail()) {
+                                              const wvec* __restrict__ wsrc, void* lds, Hooks&& hk) {
     B16Act act;
     b16_from_tiles(act, in);
-    gemm_b16_dispatch(kbp, acc, act, OT, wsrc, (v8bf*)lds, epi);
+    gemm_b16_dispatch(kbp, acc, act, OT, wsrc, (v8bf*)lds, hk);
   }
 };

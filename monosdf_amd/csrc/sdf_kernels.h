@@ -63,6 +63,158 @@ __device__ __forceinline__ float sdf_row_dot(const v4f (&in)[MT], const msdf_pla
 }
 
 // ---------------------------------------------------------------------------
+// Product hooks (protocol: mlp_core.h, NoHooks).  Pointers are lane pointers (row of the lane's point + 4 q);
+// tile t of the row sits at p + 16 t.  Results to be stored wait in registers until the next pre() / drain().
+// ---------------------------------------------------------------------------
+struct PendingStores {
+  float* dst;
+  v4f s0, s1;
+  int t0, n;
+  __device__ __forceinline__ void issue() {
+    if (n > 0) *(v4f*)(dst + 16 * t0) = s0;
+    if (n > 1) *(v4f*)(dst + 16 * t0 + 16) = s1;
+    n = 0;
+  }
+};
+
+// h = softplus(a) in place (forward kernel: nothing is saved)
+template <class Core>
+struct SoftplusHooks {
+  __device__ __forceinline__ void pre(const int, const int) {}
+  __device__ __forceinline__ void post(const int, const int, const bool pair, v4f& a0, v4f& a1) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a0[r] = Core::softplus(a0[r]);
+    if (pair) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a1[r] = Core::softplus(a1[r]);
+    }
+  }
+  __device__ __forceinline__ void drain() {}
+};
+
+// h = softplus(a) in place and saved to H (forward chain of the fwd+grad kernel)
+template <class Core>
+struct SoftplusSaveHooks {
+  PendingStores st;
+  __device__ __forceinline__ SoftplusSaveHooks(float* H) { st.dst = H; st.n = 0; st.t0 = 0; }
+  __device__ __forceinline__ void pre(const int, const int) { st.issue(); }
+  __device__ __forceinline__ void post(const int o0, const int, const bool pair, v4f& a0, v4f& a1) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a0[r] = Core::softplus(a0[r]);
+    st.s0 = a0; st.t0 = o0; st.n = 1;
+    if (pair) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a1[r] = Core::softplus(a1[r]);
+      st.s1 = a1; st.n = 2;
+    }
+  }
+  __device__ __forceinline__ void drain() { st.issue(); }
+};
+
+// gradient sweep of the fwd+grad kernel: g -> p = s g with s = 1 - exp(-100 h), h loaded from H; p saved to PM.
+// Tiles >= ot (the input block behind a skip layer's hidden tiles; ot == 0: no epilogue at all) are left alone.
+struct GradSweepHooks {
+  const float* H;
+  int ot;
+  bool save;
+  v4f h0, h1;
+  PendingStores st;
+  __device__ __forceinline__ GradSweepHooks(const float* H_, float* PM, const int ot_, const bool save_)
+      : H(H_), ot(ot_), save(save_) { st.dst = PM; st.n = 0; st.t0 = 0; }
+  __device__ __forceinline__ void pre(const int o0, const int o1) {
+    st.issue();
+    if (ot > 0) {
+      h0 = *(const v4f*)(H + 16 * (o0 < ot ? o0 : ot - 1));
+      h1 = *(const v4f*)(H + 16 * (o1 < ot ? o1 : ot - 1));
+    }
+  }
+  __device__ __forceinline__ void post(const int o0, const int o1, const bool pair, v4f& a0, v4f& a1) {
+    if (o0 < ot) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a0[r] = (1.0f - one_minus_sigmoid_from_h(h0[r])) * a0[r];
+      st.s0 = a0; st.t0 = o0; st.n = save ? 1 : 0;
+      if (pair && o1 < ot) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a1[r] = (1.0f - one_minus_sigmoid_from_h(h1[r])) * a1[r];
+        st.s1 = a1; st.n = save ? 2 : 0;
+      }
+    }
+  }
+  __device__ __forceinline__ void drain() { st.issue(); }
+};
+
+// sweep up of the double backward: p-bar -> q-bar = s p-bar in place, t = 100 (1 - s) p p-bar saved to T
+struct SweepUpHooks {
+  const float* H;
+  const float* PM;
+  int ot;
+  v4f h0, h1, p0, p1;
+  PendingStores st;
+  __device__ __forceinline__ SweepUpHooks(const float* H_, const float* PM_, float* T, const int ot_)
+      : H(H_), PM(PM_), ot(ot_) { st.dst = T; st.n = 0; st.t0 = 0; }
+  __device__ __forceinline__ void pre(const int o0, const int o1) {
+    st.issue();
+    const int c0 = o0 < ot ? o0 : ot - 1, c1 = o1 < ot ? o1 : ot - 1;
+    h0 = *(const v4f*)(H + 16 * c0);
+    h1 = *(const v4f*)(H + 16 * c1);
+    p0 = *(const v4f*)(PM + 16 * c0);
+    p1 = *(const v4f*)(PM + 16 * c1);
+  }
+  static __device__ __forceinline__ void tile(const v4f h, const v4f p, v4f& a, v4f& tt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float u = one_minus_sigmoid_from_h(h[r]);
+      const float pb = a[r];
+      tt[r] = 100.0f * u * p[r] * pb;   // s-bar * softplus''  with  p = s q
+      a[r] = (1.0f - u) * pb;
+    }
+  }
+  __device__ __forceinline__ void post(const int o0, const int, const bool pair, v4f& a0, v4f& a1) {
+    tile(h0, p0, a0, st.s0);
+    st.t0 = o0; st.n = 1;
+    if (pair) {
+      tile(h1, p1, a1, st.s1);
+      st.n = 2;
+    }
+  }
+  __device__ __forceinline__ void drain() { st.issue(); }
+};
+
+// sweep down: h-bar -> a-bar = h-bar s + t in place, saved to AB.  Tiles >= ot are left alone (ot == 0: none).
+struct SweepDownHooks {
+  const float* H;
+  const float* T;
+  int ot;
+  v4f h0, h1, t0, t1;
+  PendingStores st;
+  __device__ __forceinline__ SweepDownHooks(const float* H_, const float* T_, float* AB, const int ot_)
+      : H(H_), T(T_), ot(ot_) { st.dst = AB; st.n = 0; st.t0 = 0; }
+  __device__ __forceinline__ void pre(const int o0, const int o1) {
+    st.issue();
+    if (ot > 0) {
+      const int c0 = o0 < ot ? o0 : ot - 1, c1 = o1 < ot ? o1 : ot - 1;
+      h0 = *(const v4f*)(H + 16 * c0);
+      h1 = *(const v4f*)(H + 16 * c1);
+      t0 = *(const v4f*)(T + 16 * c0);
+      t1 = *(const v4f*)(T + 16 * c1);
+    }
+  }
+  __device__ __forceinline__ void post(const int o0, const int o1, const bool pair, v4f& a0, v4f& a1) {
+    if (o0 < ot) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a0[r] = a0[r] * (1.0f - one_minus_sigmoid_from_h(h0[r])) + t0[r];
+      st.s0 = a0; st.t0 = o0; st.n = 1;
+      if (pair && o1 < ot) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a1[r] = a1[r] * (1.0f - one_minus_sigmoid_from_h(h1[r])) + t1[r];
+        st.s1 = a1; st.n = 2;
+      }
+    }
+  }
+  __device__ __forceinline__ void drain() { st.issue(); }
+};
+
+// ---------------------------------------------------------------------------
 // F: forward only, sdf only (get_sdf_vals; reference network.py:131-137 / 307-309)
 // ---------------------------------------------------------------------------
 template <class Core>
@@ -88,10 +240,7 @@ __device__ __forceinline__ void sdf_forward_body(const msdf_plan_t& plan, const 
       place_tiles(in, L.skip_tile, in0, in0_tiles);
     }
     load_bias(acc, bpack + L.bias_off, L.ot, c.q);
-    Core::gemm(L.ktp, acc, in, L.ot, wpack + L.wf_off, lds, [](const int, v4f& v) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = Core::softplus(v[r]);
-    });
+    Core::gemm(L.ktp, acc, in, L.ot, wpack + L.wf_off, lds, SoftplusHooks<Core>());
 #pragma unroll
     for (int t = 0; t < MT; ++t) in[t] = (t < L.ot) ? acc[t] : V4ZERO;
   }
@@ -140,11 +289,7 @@ __device__ __forceinline__ void sdf_fwd_grad_body(const msdf_plan_t& plan, const
     }
     load_bias(acc, a.bpack + L.bias_off, L.ot, c.q);
     float* Hl = a.H + (size_t)L.hpre * Pp + (size_t)c.pt * (16 * L.ot) + 4 * c.q;
-    Core::gemm(L.ktp, acc, in, L.ot, (const wvec*)a.wpack + L.wf_off, lds, [Hl](const int t, v4f& v) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = Core::softplus(v[r]);
-      *(v4f*)(Hl + 16 * t) = v;
-    });
+    Core::gemm(L.ktp, acc, in, L.ot, (const wvec*)a.wpack + L.wf_off, lds, SoftplusSaveHooks<Core>(Hl));
 #pragma unroll
     for (int t = 0; t < MT; ++t) in[t] = (t < L.ot) ? acc[t] : V4ZERO;
   }
@@ -153,7 +298,7 @@ __device__ __forceinline__ void sdf_fwd_grad_body(const msdf_plan_t& plan, const
   float sdf;
   if (want_feat) {
     load_bias(acc, a.bpack + LL.bias_off, LL.ot, c.q);
-    Core::gemm(LL.ktp, acc, in, LL.ot, (const wvec*)a.wpack + LL.wf_off, lds, NoEpilogue());
+    Core::gemm(LL.ktp, acc, in, LL.ot, (const wvec*)a.wpack + LL.wf_off, lds, NoHooks());
     if (c.valid && c.pt < a.n_feat) {
       float* f = a.feat + (size_t)c.pt * (16 * plan.feat_tiles) + 4 * c.q;
 #pragma unroll
@@ -178,35 +323,40 @@ __device__ __forceinline__ void sdf_fwd_grad_body(const msdf_plan_t& plan, const
   v4f r_in[5];
 #pragma unroll
   for (int t = 0; t < 5; ++t) r_in[t] = V4ZERO;
-  for (int l = nl - 2; l >= 0; --l) {
-    const msdf_layer_t L = plan.layer[l];
-    const float* Hl = a.H + (size_t)L.hpre * Pp + (size_t)c.pt * (16 * L.ot) + 4 * c.q;
-    float* Pl = a.PM + (size_t)L.hpre * Pp + (size_t)c.pt * (16 * L.ot) + 4 * c.q;
-    // every H load before the first PM store (tile index clamped, not guarded): one exposed latency per
-    // layer instead of one load -> wait -> store round trip per tile
+  auto row = [&](const msdf_layer_t& L) { return (size_t)L.hpre * Pp + (size_t)c.pt * (16 * L.ot) + 4 * c.q; };
+  if (nl >= 2) {
+    // p of the last hidden layer: no product precedes it (g is the sdf row itself) -- every H load before
+    // the first PM store, tile index clamped instead of guarded, so that no branch separates the loads
+    const msdf_layer_t L = plan.layer[nl - 2];
+    const float* Hl = a.H + row(L);
+    float* Pl = a.PM + row(L);
     const int otl = L.ot - 1;
     v4f hh[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) hh[t] = *(const v4f*)(Hl + 16 * (t < otl ? t : otl));
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
-      v4f p = V4ZERO;
       if (t == 0 || t < L.ot) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) p[r] = (1.0f - one_minus_sigmoid_from_h(hh[t][r])) * acc[t][r];
-        if (a.save) *(v4f*)(Pl + 16 * t) = p;
+        for (int r = 0; r < 4; ++r) acc[t][r] = (1.0f - one_minus_sigmoid_from_h(hh[t][r])) * acc[t][r];
+        if (a.save) *(v4f*)(Pl + 16 * t) = acc[t];
       }
-      in[t] = p;
     }
+  }
+  for (int l = nl - 2; l >= 0; --l) {
+    const msdf_layer_t L = plan.layer[l];
+    // acc = p_l on the tiles < L.ot; the product below yields g = d sdf / d h_l and its hooks turn that into
+    // p_{l-1} (tiles behind a skip layer's hidden part are d sdf / d input: left alone)
+#pragma unroll
+    for (int t = 0; t < MT; ++t) in[t] = (t < L.ot) ? acc[t] : V4ZERO;
     zero_tiles(acc);
-    Core::gemm(L.otp, acc, in, L.kt, (const wvec*)a.wpack + L.wb_off, lds, NoEpilogue());
+    const msdf_layer_t Lp = plan.layer[l > 0 ? l - 1 : 0];
+    Core::gemm(L.otp, acc, in, L.kt, (const wvec*)a.wpack + L.wb_off, lds,
+               GradSweepHooks(a.H + row(Lp), a.PM + row(Lp), l > 0 ? Lp.ot : 0, a.save != 0));
     if (l == 0) {
       gather_tiles(r_in, acc, 0, in0_tiles);
     } else if (L.skip_tile >= 0) {
       gather_tiles(r_in, acc, L.skip_tile, in0_tiles);
-#pragma unroll
-      for (int t = 0; t < MT; ++t)
-        if (t >= L.skip_tile) acc[t] = V4ZERO;
     }
   }
   // ---------------- d sdf / d x through the PE, clamp, stores ----------------
@@ -251,10 +401,6 @@ __device__ __forceinline__ void sdf_fwd_grad_body(const msdf_plan_t& plan, const
 //   QB_l = q-bar_l (input side),  PM_l (from FG),  AB_l = a-bar_l,  H_l / IN0 (from FG).
 // ---------------------------------------------------------------------------
 typedef msdf_bw_args_t BwArgs;
-
-// H tiles of the next epilogue fetched during the last weight chunk of a product (fp32 core): as many as the
-// register file takes without spilling next to the 2 x 17 live activation tiles
-#define B_PREFETCH_TILES 8
 
 __device__ __forceinline__ void load_rbar(v4f (&rbar)[5], const msdf_plan_t& plan, const BwArgs& a,
                                           const PointCtx& c, const bool live, const float gn0, const float gn1,
@@ -314,38 +460,12 @@ __device__ __forceinline__ void sdf_backward_body(const msdf_plan_t& plan, const
       if (t < L.kt) *(v4f*)(Ql + 16 * t) = in[t];
     zero_tiles(acc);
     const size_t off = (size_t)L.hpre * Pp + (size_t)c.pt * (16 * L.ot) + 4 * c.q;
-    // The epilogue's H tiles are fetched while the last weight chunk multiplies; every other load of the
-    // epilogue (tile index clamped instead of guarded, so that no branch separates them) is issued before
-    // its first store.  Guarded loads next to the T stores had become one load -> wait -> store round trip
-    // per tile: 16 exposed memory latencies per product.
-    const int otl = L.ot - 1;
-    v4f hh[MT], pp[MT];
-    Core::gemm(L.ktp, acc, in, L.ot, (const wvec*)a.wpack + L.wf_off, lds, NoEpilogue(), [&]() {
+    // the hooks turn p-bar into q-bar of the next layer chunk by chunk, loading H / PM and storing T under the
+    // product's own matrix instructions
+    Core::gemm(L.ktp, acc, in, L.ot, (const wvec*)a.wpack + L.wf_off, lds,
+               SweepUpHooks(a.H + off, a.PM + off, a.T + off, L.ot));
 #pragma unroll
-      for (int t = 0; t < B_PREFETCH_TILES; ++t) hh[t] = *(const v4f*)(a.H + off + 16 * (t < otl ? t : otl));
-    });
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-      const int tc = t < otl ? t : otl;
-      if (!(Core::kTailPrefetch && t < B_PREFETCH_TILES)) hh[t] = *(const v4f*)(a.H + off + 16 * tc);
-      pp[t] = *(const v4f*)(a.PM + off + 16 * tc);
-    }
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-      v4f qn = V4ZERO;
-      if (t == 0 || t < L.ot) {   // tile 0 unguarded: its loads stay in the block of the others
-        v4f tt;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float u = one_minus_sigmoid_from_h(hh[t][r]);
-          const float pb = acc[t][r];
-          tt[r] = 100.0f * u * pp[t][r] * pb;   // s-bar * softplus''  with  p = s q
-          qn[r] = (1.0f - u) * pb;
-        }
-        *(v4f*)(a.T + off + 16 * t) = tt;
-      }
-      in[t] = qn;
-    }
+    for (int t = 0; t < MT; ++t) in[t] = (t < L.ot) ? acc[t] : V4ZERO;
   }
   const msdf_layer_t LL = plan.layer[nl - 1];
   {
@@ -374,58 +494,28 @@ __device__ __forceinline__ void sdf_backward_body(const msdf_plan_t& plan, const
     }
   }
   zero_tiles(acc);
-  // every product of this sweep fetches, during its last weight chunk, the H tiles of the epilogue that follows
-  v4f hnext[B_PREFETCH_TILES];
-  auto fetch_h = [&](const int l) {
-    const msdf_layer_t Ln = plan.layer[l];
-    const float* src = a.H + (size_t)Ln.hpre * Pp + (size_t)c.pt * (16 * Ln.ot) + 4 * c.q;
-#pragma unroll
-    for (int t = 0; t < B_PREFETCH_TILES; ++t)
-      hnext[t] = *(const v4f*)(src + 16 * (t < Ln.ot - 1 ? t : Ln.ot - 1));
+  // every product of this sweep yields h-bar of the layer below; its hooks turn that into a-bar of that layer
+  // (H / T loaded, AB stored under the product's matrix instructions)
+  auto down_hooks = [&](const int l) {     // hooks of the product whose output feeds layer l (l < 0: none)
+    const msdf_layer_t Ln = plan.layer[l >= 0 ? l : 0];
+    const size_t off = (size_t)Ln.hpre * Pp + (size_t)c.pt * (16 * Ln.ot) + 4 * c.q;
+    return SweepDownHooks(a.H + off, a.T + off,
+                          a.AB + (size_t)Ln.abpre * Pp + (size_t)c.pt * (16 * Ln.ot) + 4 * c.q, l >= 0 ? Ln.ot : 0);
   };
-  Core::gemm(LL.otp, acc, in, LL.kt, (const wvec*)a.wpack + LL.wb_off, lds, NoEpilogue(), [&]() {
-    if (nl >= 2) fetch_h(nl - 2);
-  });
+  Core::gemm(LL.otp, acc, in, LL.kt, (const wvec*)a.wpack + LL.wb_off, lds, down_hooks(nl - 2));
   v4f gin0[5];
 #pragma unroll
   for (int t = 0; t < 5; ++t) gin0[t] = V4ZERO;
   for (int l = nl - 2; l >= 0; --l) {
     const msdf_layer_t L = plan.layer[l];
-    const size_t off = (size_t)L.hpre * Pp + (size_t)c.pt * (16 * L.ot) + 4 * c.q;
-    float* ABl = a.AB + (size_t)L.abpre * Pp + (size_t)c.pt * (16 * L.ot) + 4 * c.q;
-    // all loads of the epilogue before its first store, clamped not guarded (see the sweep up)
-    const int otl = L.ot - 1;
-    v4f hh[MT], tt[MT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
-      const int tc = t < otl ? t : otl;
-      if (Core::kTailPrefetch && t < B_PREFETCH_TILES) hh[t] = hnext[t < B_PREFETCH_TILES ? t : 0];
-      else hh[t] = *(const v4f*)(a.H + off + 16 * tc);
-      tt[t] = *(const v4f*)(a.T + off + 16 * tc);
-    }
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-      v4f ab = V4ZERO;
-      if (t == 0 || t < L.ot) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ab[r] = acc[t][r] * (1.0f - one_minus_sigmoid_from_h(hh[t][r])) + tt[t][r];
-        *(v4f*)(ABl + 16 * t) = ab;
-      }
-      in[t] = ab;
-    }
+    for (int t = 0; t < MT; ++t) in[t] = (t < L.ot) ? acc[t] : V4ZERO;      // a-bar_l
     if (l == 0 && a.g_aux == nullptr) break;   // d loss / d x is not needed: skip the last product
     zero_tiles(acc);
-    Core::gemm(L.otp, acc, in, L.kt, (const wvec*)a.wpack + L.wb_off, lds, NoEpilogue(), [&]() {
-      if (l > 0) fetch_h(l - 1);
-    });
+    Core::gemm(L.otp, acc, in, L.kt, (const wvec*)a.wpack + L.wb_off, lds, down_hooks(l - 1));
     if (a.g_aux != nullptr) {
       if (l == 0) gather_tiles(gin0, acc, 0, in0_tiles);
       else if (L.skip_tile >= 0) gather_tiles(gin0, acc, L.skip_tile, in0_tiles);
-    }
-    if (l > 0 && L.skip_tile >= 0) {
-#pragma unroll
-      for (int t = 0; t < MT; ++t)
-        if (t >= L.skip_tile) acc[t] = V4ZERO;
     }
   }
   if (a.g_aux != nullptr && c.valid) {
