@@ -55,6 +55,76 @@ __device__ __forceinline__ void load_bias_c(v4f (&acc)[MT], const float* __restr
   for (int t = 0; t < MT; ++t) acc[t] = (t < ot) ? *(const v4f*)(b + 16 * t + 4 * q) : V4ZERO;
 }
 
+
+// ---------------------------------------------------------------------------
+// Product hooks (protocol: mlp_core.h, NoHooks); lane pointers as in sdf_kernels.h.  kt == 0 disables a hook.
+// ---------------------------------------------------------------------------
+struct ColorPending {
+  float* dst;
+  v4f s0, s1;
+  int t0, n;
+  __device__ __forceinline__ void issue() {
+    if (n > 0) *(v4f*)(dst + 16 * t0) = s0;
+    if (n > 1) *(v4f*)(dst + 16 * t0 + 16) = s1;
+    n = 0;
+  }
+};
+
+// forward: h = relu(a) in place, saved to H (input of the next layer)
+struct ReluSaveHooks {
+  int kt;
+  bool save;
+  ColorPending st;
+  __device__ __forceinline__ ReluSaveHooks(float* H, const int kt_, const bool save_) : kt(kt_), save(save_) {
+    st.dst = H; st.n = 0; st.t0 = 0;
+  }
+  __device__ __forceinline__ void pre(const int, const int) { st.issue(); }
+  __device__ __forceinline__ void post(const int o0, const int o1, const bool pair, v4f& a0, v4f& a1) {
+    if (o0 < kt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a0[r] = fmaxf(a0[r], 0.f);
+      st.s0 = a0; st.t0 = o0; st.n = save ? 1 : 0;
+      if (pair && o1 < kt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a1[r] = fmaxf(a1[r], 0.f);
+        st.s1 = a1; st.n = save ? 2 : 0;
+      }
+    }
+  }
+  __device__ __forceinline__ void drain() { st.issue(); }
+};
+
+// backward: a-bar = h-bar masked by h > 0 (h loaded from H) in place, saved to AB
+struct ReluMaskHooks {
+  const float* H;
+  int kt;
+  v4f h0, h1;
+  ColorPending st;
+  __device__ __forceinline__ ReluMaskHooks(const float* H_, float* AB, const int kt_) : H(H_), kt(kt_) {
+    st.dst = AB; st.n = 0; st.t0 = 0;
+  }
+  __device__ __forceinline__ void pre(const int o0, const int o1) {
+    st.issue();
+    if (kt > 0) {
+      h0 = *(const v4f*)(H + 16 * (o0 < kt ? o0 : kt - 1));
+      h1 = *(const v4f*)(H + 16 * (o1 < kt ? o1 : kt - 1));
+    }
+  }
+  __device__ __forceinline__ void post(const int o0, const int o1, const bool pair, v4f& a0, v4f& a1) {
+    if (o0 < kt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a0[r] = (h0[r] > 0.f) ? a0[r] : 0.f;
+      st.s0 = a0; st.t0 = o0; st.n = 1;
+      if (pair && o1 < kt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a1[r] = (h1[r] > 0.f) ? a1[r] : 0.f;
+        st.s1 = a1; st.n = 2;
+      }
+    }
+  }
+  __device__ __forceinline__ void drain() { st.issue(); }
+};
+
 template <class Core>
 __device__ __forceinline__ void color_forward_body(const msdf_plan_t& plan, const ColorFwdArgs& a, void* lds) {
   typedef typename Core::wvec wvec;
@@ -85,24 +155,21 @@ __device__ __forceinline__ void color_forward_body(const msdf_plan_t& plan, cons
         if (t < misc_tiles) *(v4f*)(a.MISC + (size_t)pt * (16 * misc_tiles) + 16 * t + 4 * q) = m[t];
     }
   }
+  // every product but the last hands relu(output) to the next layer through its hooks (saved to H on the way)
+  auto next_hooks = [&](const int u) {     // hooks of the product that feeds unit u (u >= nu: none)
+    const msdf_layer_t Ln = plan.layer[u < nu ? u : 0];
+    return ReluSaveHooks(a.H + (size_t)Ln.hpre * Pp + (size_t)pt * (16 * Ln.kt) + 4 * q, u < nu ? Ln.kt : 0,
+                         a.save != 0);
+  };
   const msdf_layer_t U1 = plan.layer[1];
-  Core::gemm(U1.ktp, acc, in, U1.ot, (const wvec*)a.wpack + U1.wf_off, lds, NoHooks());
+  Core::gemm(U1.ktp, acc, in, U1.ot, (const wvec*)a.wpack + U1.wf_off, lds, next_hooks(2));
   // ---- hidden layers
   for (int u = 2; u < nu; ++u) {
     const msdf_layer_t L = plan.layer[u];
-    float* Hl = a.H + (size_t)L.hpre * Pp + (size_t)pt * (16 * L.kt) + 4 * q;
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
-      v4f h = V4ZERO;
-      if (t < L.kt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) h[r] = fmaxf(acc[t][r], 0.f);
-        if (a.save) *(v4f*)(Hl + 16 * t) = h;
-      }
-      in[t] = h;
-    }
+    for (int t = 0; t < MT; ++t) in[t] = (t < L.kt) ? acc[t] : V4ZERO;
     load_bias_c(acc, a.bpack + L.bias_off, L.ot, q);
-    Core::gemm(L.ktp, acc, in, L.ot, (const wvec*)a.wpack + L.wf_off, lds, NoHooks());
+    Core::gemm(L.ktp, acc, in, L.ot, (const wvec*)a.wpack + L.wf_off, lds, next_hooks(u + 1));
   }
   // ---- output activation: slots 0..2 sit in tile 0, quarter 0
   if (valid && q == 0) {
@@ -147,26 +214,14 @@ __device__ __forceinline__ void color_backward_body(const msdf_plan_t& plan, con
   for (int u = nu - 1; u >= 2; --u) {
     const msdf_layer_t L = plan.layer[u];
     zero_tiles(acc);
-    Core::gemm(L.otp, acc, in, L.kt, (const wvec*)a.wpack + L.wb_off, lds, NoHooks());
-    // acc = h-bar of this layer's input = output of unit u-1 (u-1 == 1 means the first layer)
-    const float* Hl = a.H + (size_t)L.hpre * Pp + (size_t)pt * (16 * L.kt) + 4 * q;
+    // the product yields h-bar of this layer's input = output of unit u-1 (u-1 == 1 means the first layer);
+    // its hooks mask it with the saved activation and store it as a-bar of that unit
     const msdf_layer_t Lp = plan.layer[(u - 1 == 1) ? 0 : u - 1];
-    float* ABl = a.AB + (size_t)Lp.abpre * Pp + (size_t)pt * (16 * Lp.ot) + 4 * q;
-    // every H load before the first AB store, tile index clamped instead of guarded (sdf_kernels.h, sweep up)
-    const int ktl = L.kt - 1;
-    v4f hh[MT];
+    Core::gemm(L.otp, acc, in, L.kt, (const wvec*)a.wpack + L.wb_off, lds,
+               ReluMaskHooks(a.H + (size_t)L.hpre * Pp + (size_t)pt * (16 * L.kt) + 4 * q,
+                             a.AB + (size_t)Lp.abpre * Pp + (size_t)pt * (16 * Lp.ot) + 4 * q, L.kt));
 #pragma unroll
-    for (int t = 0; t < MT; ++t) hh[t] = *(const v4f*)(Hl + 16 * (t < ktl ? t : ktl));
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-      v4f ab = V4ZERO;
-      if (t == 0 || t < L.kt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ab[r] = (hh[t][r] > 0.f) ? acc[t][r] : 0.f;
-        *(v4f*)(ABl + 16 * t) = ab;
-      }
-      in[t] = ab;
-    }
+    for (int t = 0; t < MT; ++t) in[t] = (t < L.kt) ? acc[t] : V4ZERO;
   }
   // ---- first layer: gradient of the feature tiles and of the misc block
   const msdf_layer_t U0 = plan.layer[0];

@@ -320,9 +320,21 @@ __device__ __forceinline__ void sdf_fwd_grad_body(const msdf_plan_t& plan, const
 #pragma unroll
   for (int t = 0; t < MT; ++t)
     acc[t] = (t < LL.kt) ? *(const v4f*)(a.bpack + plan.wsdf_off + 16 * t + 4 * c.q) : V4ZERO;
-  v4f r_in[5];
+  // d sdf / d input arrives twice (behind the skip layer's hidden tiles and from layer 0); each arrival goes
+  // through the PE Jacobian at once -- 3 floats + the aux tiles stay live across the products, not 5 tiles
+  float n0 = 0.f, n1 = 0.f, n2 = 0.f;
+  v4f r_aux[2] = {V4ZERO, V4ZERO};
+  auto take_input_grad = [&](const int base) {
+    v4f r[5];
 #pragma unroll
-  for (int t = 0; t < 5; ++t) r_in[t] = V4ZERO;
+    for (int t = 0; t < 5; ++t) r[t] = V4ZERO;
+    gather_tiles(r, acc, base, in0_tiles);
+    float m0, m1, m2;
+    pe_jacobian_transpose(r, c.x0, c.x1, c.x2, plan.n_freqs, m0, m1, m2);
+    n0 += m0; n1 += m1; n2 += m2;
+    r_aux[0] += r[3];
+    r_aux[1] += r[4];
+  };
   auto row = [&](const msdf_layer_t& L) { return (size_t)L.hpre * Pp + (size_t)c.pt * (16 * L.ot) + 4 * c.q; };
   if (nl >= 2) {
     // p of the last hidden layer: no product precedes it (g is the sdf row itself) -- every H load before
@@ -353,15 +365,10 @@ __device__ __forceinline__ void sdf_fwd_grad_body(const msdf_plan_t& plan, const
     const msdf_layer_t Lp = plan.layer[l > 0 ? l - 1 : 0];
     Core::gemm(L.otp, acc, in, L.kt, (const wvec*)a.wpack + L.wb_off, lds,
                GradSweepHooks(a.H + row(Lp), a.PM + row(Lp), l > 0 ? Lp.ot : 0, a.save != 0));
-    if (l == 0) {
-      gather_tiles(r_in, acc, 0, in0_tiles);
-    } else if (L.skip_tile >= 0) {
-      gather_tiles(r_in, acc, L.skip_tile, in0_tiles);
-    }
+    if (l == 0) take_input_grad(0);
+    else if (L.skip_tile >= 0) take_input_grad(L.skip_tile);
   }
-  // ---------------- d sdf / d x through the PE, clamp, stores ----------------
-  float n0, n1, n2;
-  pe_jacobian_transpose(r_in, c.x0, c.x1, c.x2, plan.n_freqs, n0, n1, n2);
+  // ---------------- clamp, stores ----------------
   bool is_clamped = false;
   if (a.clamp_radius > 0.f && c.pt < a.n_clamp) {
     const float nx = sqrtf(c.x0 * c.x0 + c.x1 * c.x1 + c.x2 * c.x2);
@@ -386,7 +393,7 @@ __device__ __forceinline__ void sdf_fwd_grad_body(const msdf_plan_t& plan, const
 #pragma unroll
       for (int t = 0; t < 2; ++t)
         if (t < plan.aux_tiles) {
-          v4f v = r_in[3 + t];
+          v4f v = r_aux[t];
           if (is_clamped) v = V4ZERO;
           *(v4f*)(a.r_aux + (size_t)c.pt * aw + 16 * t + 4 * c.q) = v;
         }
@@ -503,9 +510,9 @@ __device__ __forceinline__ void sdf_backward_body(const msdf_plan_t& plan, const
                           a.AB + (size_t)Ln.abpre * Pp + (size_t)c.pt * (16 * Ln.ot) + 4 * c.q, l >= 0 ? Ln.ot : 0);
   };
   Core::gemm(LL.otp, acc, in, LL.kt, (const wvec*)a.wpack + LL.wb_off, lds, down_hooks(nl - 2));
-  v4f gin0[5];
+  v4f g_in_aux[5];      // only the aux tiles (hash-grid features) of d loss / d input are an output
 #pragma unroll
-  for (int t = 0; t < 5; ++t) gin0[t] = V4ZERO;
+  for (int t = 0; t < 5; ++t) g_in_aux[t] = V4ZERO;
   for (int l = nl - 2; l >= 0; --l) {
     const msdf_layer_t L = plan.layer[l];
 #pragma unroll
@@ -514,15 +521,15 @@ __device__ __forceinline__ void sdf_backward_body(const msdf_plan_t& plan, const
     zero_tiles(acc);
     Core::gemm(L.otp, acc, in, L.kt, (const wvec*)a.wpack + L.wb_off, lds, down_hooks(l - 1));
     if (a.g_aux != nullptr) {
-      if (l == 0) gather_tiles(gin0, acc, 0, in0_tiles);
-      else if (L.skip_tile >= 0) gather_tiles(gin0, acc, L.skip_tile, in0_tiles);
+      if (l == 0) gather_tiles(g_in_aux, acc, plan.e_tiles, plan.aux_tiles);
+      else if (L.skip_tile >= 0) gather_tiles(g_in_aux, acc, L.skip_tile + plan.e_tiles, plan.aux_tiles);
     }
   }
   if (a.g_aux != nullptr && c.valid) {
     const int aw = 16 * plan.aux_tiles;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
-      if (t < plan.aux_tiles) *(v4f*)(a.g_aux + (size_t)c.pt * aw + 16 * t + 4 * c.q) = gin0[3 + t];
+      if (t < plan.aux_tiles) *(v4f*)(a.g_aux + (size_t)c.pt * aw + 16 * t + 4 * c.q) = g_in_aux[t];
   }
 }
 
