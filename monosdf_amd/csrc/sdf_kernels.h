@@ -488,17 +488,20 @@ __device__ __forceinline__ void sdf_backward_body(const msdf_plan_t& plan, const
   const bool has_feat = (a.g_feat != nullptr) && c.valid && c.pt < a.n_feat;
   {
     float* ABl = a.AB + (size_t)LL.abpre * Pp + (size_t)c.pt * (16 * LL.ot) + 4 * c.q;
+    // every load before the first store (as in the hooks: a store next to each load is one memory round trip per tile)
+    const float* gf = a.g_feat + (size_t)(has_feat ? c.pt : 0) * (16 * plan.feat_tiles) + 4 * c.q;
+    const int ftl = plan.feat_tiles - 1;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
       v4f v = V4ZERO;
-      if (t < plan.feat_tiles) {
-        if (has_feat) v = *(const v4f*)(a.g_feat + (size_t)c.pt * (16 * plan.feat_tiles) + 16 * t + 4 * c.q);
-      } else if (t == plan.feat_tiles) {
-        if (c.q == 0) v.x = gs;
-      }
-      if (t < LL.ot) *(v4f*)(ABl + 16 * t) = v;
+      if (a.g_feat != nullptr && ftl >= 0) v = *(const v4f*)(gf + 16 * (t < ftl ? t : ftl));
+      if (!has_feat || t >= plan.feat_tiles) v = V4ZERO;
+      if (t == plan.feat_tiles && c.q == 0) v.x = gs;
       in[t] = v;
     }
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+      if (t < LL.ot) *(v4f*)(ABl + 16 * t) = in[t];
   }
   zero_tiles(acc);
   // every product of this sweep yields h-bar of the layer below; its hooks turn that into a-bar of that layer

@@ -85,7 +85,11 @@ def test_fullsize_directional_derivative():
     gen = torch.Generator(device='cuda').manual_seed(3)
     for name in ('rendering_network.lin1.bias', 'rendering_network.lin0.weight_g'):
         p = params[name]
-        d = torch.randn(p.shape, device='cuda', generator=gen)
+        # direction = the gradient's own plus half a random one: the loss (~0.5) is an fp32 scalar, so a central
+        # difference over 2 eps resolves derivatives down to ~6e-8 / 4e-3 = 1.5e-5 -- a purely random direction in
+        # a 256-dimensional parameter has a derivative of that size (the test then compares rounding noise)
+        r = torch.randn(p.shape, device='cuda', generator=gen)
+        d = p.grad / p.grad.norm() + 0.5 * r / r.norm()
         d /= d.norm()
         analytic = (p.grad * d).sum().item()
         numeric = _central_difference(p, d, 2e-3, step_loss)
