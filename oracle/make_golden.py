@@ -38,6 +38,10 @@ def conf_from_spec(spec):
         c['white_bkgd'] = True
     if spec.get('per_image_code', False):
         c['rendering_network']['per_image_code'] = True
+    if spec.get('render_mode', 'idr') == 'nerf':
+        # view directions + features only (reference network.py:437-440); no conf of the reference uses it
+        c['rendering_network']['mode'] = 'nerf'
+        c['rendering_network']['d_in'] = 3
     return c
 
 
@@ -83,6 +87,11 @@ CASES = {
                                 white_bkgd=True),
     'mlp_w64_code_train': dict(kind='mlp', width=64, n_rays=12, jitter=0.3, training=True, grads=True,
                                per_image_code=True),
+    # if_hdr = True (6 of the reference's confs): ReLU instead of the sigmoid on the colour output
+    'mlp_w64_hdr_train': dict(kind='mlp', width=64, n_rays=12, jitter=0.3, training=True, grads=True, if_hdr=True),
+    'mlp_w64_hdr_eval': dict(kind='mlp', width=64, n_rays=12, jitter=0.3, training=False, if_hdr=True, ray_seed=4),
+    'mlp_w64_nerf_train': dict(kind='mlp', width=64, n_rays=12, jitter=0.3, training=True, grads=True,
+                               render_mode='nerf'),
     'gridless_w128_train': dict(kind='gridless', width=128, n_rays=8, jitter=0.3, training=True, grads='digest'),
     'grid_small_train': dict(kind='grid', width=64, n_rays=12, jitter=0.3, training=True, grads=True,
                              num_levels=4, logmap=10, end_size=64),
@@ -106,7 +115,7 @@ def run_case(name, spec):
                              sdf_scale=spec.get('sdf_scale', 1.0))
     inputs, indices = make_inputs(spec)
     pixel = not spec.get('image_mode', False)
-    model = ref_loader.build_model(conf, state, training=spec['training'])
+    model = ref_loader.build_model(conf, state, training=spec['training'], if_hdr=spec.get('if_hdr', False))
     rounds = [0]
     orig = model.implicit_network.get_sdf_vals
 

@@ -34,7 +34,8 @@ def run(c, dtype, sampler_sdf_fp32=False):
         with torch.no_grad():
             z_override = mo.error_bound_sampler(state, c.conf, inputs['ray_dirs'], inputs['ray_cam_loc'], c.training,
                                                 noise, sdf_fn=fn)
-    out = mo.render(state, c.conf, inputs, c.indices, c.pixel, c.training, noise, z_override=z_override)
+    out = mo.render(state, c.conf, inputs, c.indices, c.pixel, c.training, noise, z_override=z_override,
+                    if_hdr=c.spec.get('if_hdr', False))
     grads = {}
     if c.training:
         names = [n for n in state if state[n].requires_grad]

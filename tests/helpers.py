@@ -24,6 +24,9 @@ def conf_from_spec(spec):
         c['white_bkgd'] = True
     if spec.get('per_image_code', False):
         c['rendering_network']['per_image_code'] = True
+    if spec.get('render_mode', 'idr') == 'nerf':
+        c['rendering_network']['mode'] = 'nerf'
+        c['rendering_network']['d_in'] = 3
     return c
 
 

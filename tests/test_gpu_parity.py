@@ -18,7 +18,7 @@ TOL = 1e-4
 def _model(case, training=None, precision='fp32'):
     from monosdf_amd.conf import ConfigTree
     from monosdf_amd.model.network import MonoSDFNetwork
-    m = MonoSDFNetwork(ConfigTree.from_dict(case.conf))
+    m = MonoSDFNetwork(ConfigTree.from_dict(case.conf), if_hdr=case.spec.get('if_hdr', False))
     m.load_state_dict({k: v.clone() for k, v in case.state.items()}, strict=True)
     m.train(case.training if training is None else training)
     return m.cuda().set_precision(precision)

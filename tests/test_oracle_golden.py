@@ -21,7 +21,8 @@ def test_forward_and_grads_match_reference(name):
     c = Case(name)
     state = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in c.state.items()}
     trace = {}
-    out = mo.render(state, c.conf, c.inputs, c.indices, c.pixel, c.training, c.noise)
+    out = mo.render(state, c.conf, c.inputs, c.indices, c.pixel, c.training, c.noise,
+                    if_hdr=c.spec.get('if_hdr', False))
     assert set(out) == set(c.out)
     for k, ref in c.out.items():
         assert out[k].shape == ref.shape, k
