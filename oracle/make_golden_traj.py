@@ -26,7 +26,19 @@ BASE = dict(width=64, weight_seed=11, jitter=0.0, n_rays=64, steps=200, lr=5.0e-
                       normal_cos_weight=0.05))
 # two runs: the confs' initial beta (the sampler converges in one round throughout), and a sharp start where beta
 # falls to 6e-4 and the sampler needs 2 to 4 rounds per step
-SPECS = {'traj_w64': dict(BASE, beta=0.1), 'traj_w64_sharp': dict(BASE, beta=0.02)}
+SPECS = {'traj_w64': dict(BASE, beta=0.1), 'traj_w64_sharp': dict(BASE, beta=0.02),
+         # the hash-grid model (4 levels, 2^10 entries: the reference's Python wiring over the restated kernels of
+         # ref_loader.FakeHashBackend -- pins the wiring and Adam on the embeddings, not the kernel arithmetic)
+         'traj_grid_small': dict(BASE, beta=0.1, kind='grid', steps=120, checkpoints=(40, 80, 120),
+                                 grid=dict(num_levels=4, level_dim=2, logmap=10, base_size=16, end_size=64))}
+
+
+def conf_of(spec):
+    if spec.get('kind', 'mlp') == 'grid':
+        g = spec['grid']
+        return config.grid_config(spec['width'], spec['beta'], g['num_levels'], g['level_dim'], g['logmap'],
+                                  g['base_size'], g['end_size'])
+    return config.mlp_config(spec['width'], 8, spec['beta'])
 TERMS = ('loss', 'rgb_loss', 'eikonal_loss', 'smooth_loss', 'depth_loss', 'normal_l1', 'normal_cos')
 
 
@@ -45,7 +57,7 @@ def run(name, spec, perturb=0.0, perturb_seed=9):
     """perturb > 0: a control run -- the same reference, every initial weight multiplied by 1 + perturb * N(0,1):
     the spread two equally exact implementations show after the same steps."""
     ref_loss = make_golden_loss.load_reference_loss()
-    conf = config.mlp_config(spec['width'], 8, spec['beta'])
+    conf = conf_of(spec)
     state = synth.make_state(conf, seed=spec['weight_seed'], jitter=spec['jitter'])
     if perturb > 0:
         g = torch.Generator().manual_seed(perturb_seed)
@@ -104,10 +116,13 @@ def run(name, spec, perturb=0.0, perturb_seed=9):
     print('%s %.1f KB' % (name, os.path.getsize(out) / 1024))
 
 
-def main():
+def main(argv=()):
     for name, spec in SPECS.items():
+        if argv and name not in argv:
+            continue
         run(name, spec)
 
 
 if __name__ == '__main__':
-    main()
+    import sys
+    main(sys.argv[1:])

@@ -23,14 +23,24 @@ def _psnr(a, b):
     return -10.0 * math.log10(torch.mean((a - b) ** 2).item())
 
 
-@pytest.mark.parametrize('name', ['traj_w64', 'traj_w64_sharp'])
+def _conf(spec):
+    if spec.get('kind', 'mlp') == 'grid':
+        g = spec['grid']
+        return config.grid_config(spec['width'], spec['beta'], g['num_levels'], g['level_dim'], g['logmap'],
+                                  g['base_size'], g['end_size'])
+    return config.mlp_config(spec['width'], 8, spec['beta'])
+
+
+# traj_grid_small: the reference's Python wiring over the restated hash kernels (parity of the hash arithmetic
+# itself is unpinned: README) -- what it pins is the fused embedding scatter + Adam on the tables over 120 steps
+@pytest.mark.parametrize('name', ['traj_w64', 'traj_w64_sharp', 'traj_grid_small'])
 def test_training_trajectory_matches_reference(name, golden_dir, errlog):
     from monosdf_amd.conf import ConfigTree
     from monosdf_amd.model.loss import MonoSDFLoss
     from monosdf_amd.model.network import MonoSDFNetwork
     z = np.load('%s/%s.npz' % (golden_dir, name))
     spec = dict(ast.literal_eval(bytes(z['spec']).decode()))
-    conf = config.mlp_config(spec['width'], 8, spec['beta'])
+    conf = _conf(spec)
     state = synth.make_state(conf, seed=spec['weight_seed'], jitter=spec['jitter'])
     model = MonoSDFNetwork(ConfigTree.from_dict(conf))
     model.load_state_dict(state, strict=True)
