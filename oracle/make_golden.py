@@ -99,6 +99,11 @@ CASES = {
                             num_levels=4, logmap=10, end_size=64),
     'mlp_w256_eval': dict(kind='mlp', width=256, n_rays=8, jitter=0.05, training=False),
     'mlp_w256_train': dict(kind='mlp', width=256, n_rays=8, jitter=0.05, training=True, grads='digest'),
+    # 128 rays x 98 samples + eikonal points = 12,800 points: 200 workgroups of the MLP kernels, ragged last tile
+    'mlp_w256_train_r128': dict(kind='mlp', width=256, n_rays=128, jitter=0.05, training=True, grads='digest',
+                                ray_seed=9),
+    # the reference's full grid configuration (16 levels, 2^19 entries per hashed level, scannetGrids.conf)
+    'grid_full_eval': dict(kind='grid', width=256, n_rays=8, jitter=0.3, training=False, ray_seed=5),
 }
 
 
