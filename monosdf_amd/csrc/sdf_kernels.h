@@ -277,7 +277,7 @@ __device__ __forceinline__ void sdf_fwd_grad_body(const msdf_plan_t& plan, const
     }
   }
   // workgroup-uniform on purpose: the gemm below contains barriers and cooperative weight staging
-  const bool want_feat = blockIdx.x * MLP_PTS_PER_WG < a.n_feat;
+  const bool want_feat = (int)(blockIdx.x * MLP_PTS_PER_WG) < a.n_feat;
 
   // ---------------- forward chain ----------------
   for (int l = 0; l < nl - 1; ++l) {
