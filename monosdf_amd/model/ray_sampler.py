@@ -79,7 +79,8 @@ class ErrorBoundSampler(RaySampler):
         self.scene_bounding_sphere = scene_bounding_sphere
         self.add_tiny = add_tiny
         self._last_rounds = 0
-        self._history = []        # rounds of the last few calls
+        self._history = []        # rounds of the last HISTORY calls
+        self._after_miss = 0      # calls left in which all max_total_iters rounds are enqueued (see guess_rounds)
         self._pending = None
         self._eval_columns = {}
         # speculation bookkeeping (bench.py reports it): calls, passes repeated because too few rounds were
@@ -160,6 +161,7 @@ class ErrorBoundSampler(RaySampler):
         if ran > k:
             self.stats['repeats'] += 1
             self._note_rounds(k + 1)
+            self._after_miss = self.HISTORY
             return False
         self.stats['idle_rounds'] += k - ran
         self._note_rounds(ran)
@@ -173,11 +175,20 @@ class ErrorBoundSampler(RaySampler):
             return True
         return self._resolve()
 
+    HISTORY = 32
+
     def _note_rounds(self, rounds):
         self._last_rounds = rounds
-        self._history = (self._history + [rounds])[-8:]
+        self._history = (self._history + [rounds])[-self.HISTORY:]
 
     def guess_rounds(self):
+        """Rounds to enqueue for the next call without reading a flag back.  An idle round costs three empty
+        launches (~15 us), a round too few costs the whole forward pass again (~10 ms at 1024 rays), so the guess
+        errs upwards: the most demanding of the last HISTORY calls, and all max_total_iters rounds for HISTORY calls
+        after every miss (small beta: most steps need 2 rounds, one in seven needs 5 -- bench.py, sharp_state)."""
+        if self._after_miss > 0:
+            self._after_miss -= 1
+            return self.max_total_iters
         return max(self._history) if self._history else 1
 
     def sample(self, ray_dirs, cam_loc, model, want_points=True, speculate=0, beta0=None):

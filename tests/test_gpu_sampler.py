@@ -298,7 +298,10 @@ def test_round_count_guessed_from_history(name, history):
     if c.training:
         for n in ref_grads:
             assert torch.equal(grads[n], ref_grads[n]), n
-    assert m.ray_sampler.guess_rounds() >= c.rounds          # the next call will enqueue enough
+    nxt = m.ray_sampler.guess_rounds()
+    assert nxt >= c.rounds                                   # the next call will enqueue enough
+    if guess < c.rounds:
+        assert nxt == m.ray_sampler.max_total_iters          # and after a miss: all rounds, for a while
 
 
 @pytest.mark.parametrize('name', ['mlp_w64_eval', 'mlp_w64_eval_k3', 'mlp_w64_eval_k5nc'])
