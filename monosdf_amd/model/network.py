@@ -161,6 +161,7 @@ class _SdfBase(_FusedNet):
                 x, enc.embeddings, flat_w, flat_b, wpack, bpack, fused,
                 (enc.num_levels, enc.level_dim, enc.log2_scale, int(enc.base_resolution)), int(n_clamp), int(n_feat),
                 self.sphere_scale, bool(save), ns, float(self.divide_factor))
+            feat = self._trim_features(feat)
             return (sdf, feat, nrm) if split is None else (sdf, feat, nrm, nrm_b)
         aux, handle = None, None
         if self.aux_active:
@@ -176,9 +177,15 @@ class _SdfBase(_FusedNet):
             through_grid = self.encoding.input_gradient(handle, r_aux) * (0.5 / self.divide_factor)
             nrm = nrm + through_grid[:ns]
             nrm_b = nrm_b + through_grid[ns:]
+        feat = self._trim_features(feat)
         if split is None:
             return sdf, feat, nrm
         return sdf, feat, nrm, nrm_b
+
+    def _trim_features(self, feat):
+        """The kernels write whole 16-slot tiles; the caller gets feature_vector_size columns (a view)."""
+        F = self.feature_vector_size
+        return feat if feat.shape[1] == F else feat[:, :F]
 
     def _pad_aux(self, aux):
         """The kernels read whole 16-slot tiles of grid features."""

@@ -475,12 +475,25 @@ class ColorMlpFunction(torch.autograd.Function):
         x = _need_cuda(x.detach(), 'points')
         dirs = _need_cuda(dirs.detach(), 'view dirs')
         nrm = _need_cuda(nrm.detach(), 'normals')
-        feat = _need_cuda(feat.detach(), 'features')
+        feat = feat.detach()
         P = x.shape[0]
         P_pad = _pad64(max(P, 1))
         dev = x.device
-        if feat.shape[1] != 16 * plan.layer[0].kt:
-            raise RuntimeError('monosdf_amd: feature width must be a multiple of 16')
+        # the kernels read whole 16-slot tiles of the feature vector: a narrower tensor is taken as the view of the
+        # SDF kernel's padded rows it normally is (ImplicitNetwork.evaluate slices them to feature_vector_size; the
+        # pad columns are zero there), otherwise padded with zeros
+        Fk = 16 * plan.layer[0].kt
+        ctx.feat_cols = feat.shape[1]
+        if feat.shape[1] > Fk or Fk - feat.shape[1] >= 16:
+            raise RuntimeError('monosdf_amd: feature width %d does not fit the colour network plan (%d slots)'
+                               % (feat.shape[1], Fk))
+        if feat.shape[1] < Fk:
+            if feat.is_cuda and feat.dim() == 2 and feat.stride() == (Fk, 1) and \
+                    feat.untyped_storage().nbytes() // 4 - feat.storage_offset() >= P * Fk:
+                feat = feat.as_strided((P, Fk), (Fk, 1))
+            else:
+                feat = torch.nn.functional.pad(feat, (0, Fk - feat.shape[1]))
+        feat = _need_cuda(feat, 'features')
         room = feat.untyped_storage().nbytes() // 4 - feat.storage_offset()
         if room < P_pad * feat.shape[1]:
             # the weight-gradient GEMM streams whole 64-point tiles: give the tail rows finite values
@@ -542,6 +555,8 @@ class ColorMlpFunction(torch.autograd.Function):
         g_code = None
         if ctx.has_code:
             g_code = g_misc[:, 48:].reshape(P // ctx.spr, ctx.spr, -1).sum(1)
+        if ctx.feat_cols < g_feat.shape[1]:
+            g_feat = g_feat[:, :ctx.feat_cols]
         return (None, None, g_nrm, g_feat, g_code, grad[:mp.n_w], grad[mp.n_w:], None, None, None, None, None)
 
 

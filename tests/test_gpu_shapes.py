@@ -1,0 +1,84 @@
+"""Network geometries the goldens do not reach: widths that are not multiples of 16 (padded tiles), odd tile counts
+(a product's last weight chunk holds ONE out tile), networks with and without the skip layer, 2 to 8 layers.
+The fused kernels (forward + gradient, double backward with all weight gradients, full training forward) against the
+CPU oracle -- which test_oracle_golden.py pins to the reference on the golden geometries; these geometries are the
+same code of the oracle with other sizes."""
+import pytest
+import torch
+
+from helpers import TOL, rel_err
+from oracle import config, synth
+
+pytestmark = pytest.mark.gpu
+
+# (width, depth): 48 = 3 tiles (odd), 100 = 7 tiles with 12 padded slots, 176 = 11 tiles, 256 with 2 layers (the
+# hash-grid configuration's MLP without the grid)
+SHAPES = [(48, 2), (48, 5), (100, 3), (100, 8), (176, 5), (256, 2)]
+
+
+def _build(width, depth, precision):
+    from monosdf_amd.conf import ConfigTree
+    from monosdf_amd.model.network import MonoSDFNetwork
+    conf = config.mlp_config(width, depth)
+    state = synth.make_state(conf, seed=width + depth, jitter=0.3)
+    m = MonoSDFNetwork(ConfigTree.from_dict(conf))
+    m.load_state_dict({k: v.clone() for k, v in state.items()}, strict=True)
+    return conf, state, m.cuda().set_precision(precision)
+
+
+@pytest.mark.parametrize('width,depth', SHAPES)
+def test_sdf_network_forward_gradient_and_double_backward(width, depth):
+    from oracle import monosdf_oracle as mo
+    conf, state, m = _build(width, depth, 'fp32')
+    m.train()
+    g = torch.Generator().manual_seed(11)
+    P = 64 * 3 + 21                                    # ragged last tile
+    x = (torch.rand(P, 3, generator=g) * 2 - 1) * 1.2
+    F = conf['feature_vector_size']
+    ca, cb, cc = torch.randn(P, 1, generator=g), torch.randn(P, F, generator=g) * 0.1, torch.randn(P, 3, generator=g)
+    st = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in state.items()}
+    sdf_o, feat_o, grad_o = mo.get_outputs(st, conf, x)
+    sdf, feat, grad = m.implicit_network.get_outputs(x.cuda())
+    assert rel_err(sdf, sdf_o) < TOL and rel_err(feat, feat_o) < TOL and rel_err(grad, grad_o) < TOL
+    loss_o = (ca * sdf_o).sum() + (cb * feat_o).sum() + (cc * grad_o).sum()
+    names = [n for n in st if n.startswith('implicit_network.lin')]
+    g_o = torch.autograd.grad(loss_o, [st[n] for n in names])
+    loss = (ca.cuda() * sdf).sum() + (cb.cuda() * feat).sum() + (cc.cuda() * grad).sum()
+    loss.backward()
+    params = dict(m.named_parameters())
+    for n, go in zip(names, g_o):
+        # second-order sums with cancellation: the bar of the golden geometries' double-backward test
+        assert rel_err(params[n].grad, go) < 2 * TOL, (n, rel_err(params[n].grad, go))
+
+
+@pytest.mark.parametrize('width,depth', [(48, 5), (100, 3), (176, 5)])
+def test_training_forward_and_gradients(width, depth):
+    """The whole pass (sampler, both networks, compositor, eikonal block) and the gradients of the probe loss."""
+    from oracle import monosdf_oracle as mo
+    conf, state, m = _build(width, depth, 'fp32')
+    m.train()
+    n = 24
+    rays = synth.make_rays(n, seed=3, random_pose=True)
+    noise = synth.make_noise(conf, n, 128, seed=5)
+    idx = torch.arange(n) % 7
+    st = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in state.items()}
+    ref = mo.render(st, conf, rays, idx, True, True, noise)
+    m._noise = {k: v.cuda() for k, v in noise.items()}
+    out = m({k: v.cuda() for k, v in rays.items()}, idx.cuda(), if_pixel_input=True)
+    for k in ('rgb_values', 'depth_values', 'normal_map', 'weights', 'sdf', 'grad_theta'):
+        assert rel_err(out[k], ref[k]) < 5 * TOL, (k, rel_err(out[k], ref[k]))      # 1-round sampler cases: 1e-4-ish
+    loss_o = mo.probe_loss(ref)
+    names = [k for k, v in st.items() if v.requires_grad]
+    g_o = dict(zip(names, torch.autograd.grad(loss_o, [st[k] for k in names], allow_unused=True)))
+    mo.probe_loss(out).backward()
+    for k, p in m.named_parameters():
+        if g_o.get(k) is None:
+            continue
+        assert rel_err(p.grad, g_o[k]) < 5 * TOL, (k, rel_err(p.grad, g_o[k]))
+
+
+def test_too_wide_network_is_refused():
+    """257 outputs (256 features + sdf) are 17 tiles, the register layout's maximum: 272 features do not fit."""
+    with pytest.raises(RuntimeError, match='tile'):
+        _, _, m = _build(272, 2, 'fp32')
+        m.implicit_network.get_outputs(torch.zeros(64, 3, device='cuda'))
