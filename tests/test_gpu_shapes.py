@@ -82,3 +82,67 @@ def test_too_wide_network_is_refused():
     with pytest.raises(RuntimeError, match='tile'):
         _, _, m = _build(272, 2, 'fp32')
         m.implicit_network.get_outputs(torch.zeros(64, 3, device='cuda'))
+
+
+def _variant(edit, seed=21):
+    from monosdf_amd.conf import ConfigTree
+    from monosdf_amd.model.network import MonoSDFNetwork
+    conf = config.mlp_config(64, 8)
+    edit(conf)
+    state = synth.make_state(conf, seed=seed, jitter=0.3)
+    m = MonoSDFNetwork(ConfigTree.from_dict(conf))
+    m.load_state_dict({k: v.clone() for k, v in state.items()}, strict=True)
+    return conf, state, m.cuda()
+
+
+def _set(section, **kw):
+    def edit(conf):
+        conf[section].update(kw)
+    return edit
+
+
+VARIANTS = {
+    'no_positional_encoding': _set('implicit_network', multires=0),
+    'multires_4': _set('implicit_network', multires=4),
+    'skip_at_2': _set('implicit_network', skip_in=[2]),
+    'no_skip': _set('implicit_network', skip_in=[]),
+    'outside_in': _set('implicit_network', inside_outside=False),
+    'view_pe_0': _set('rendering_network', multires_view=0),
+    'view_pe_2': _set('rendering_network', multires_view=2),
+    'colour_3_hidden': _set('rendering_network', dims=[64, 64, 64]),
+    'colour_1_hidden': _set('rendering_network', dims=[64]),
+}
+
+
+@pytest.mark.parametrize('name', sorted(VARIANTS))
+def test_config_options_against_oracle(name):
+    """Options of the reference's conf files the goldens leave at their usual values: one training pass (forward
+    outputs and the gradients of the probe loss) against the oracle."""
+    from oracle import monosdf_oracle as mo
+    # weight seed 21 puts one ReLU input of the colour network's first layer at 9.9e-8 in the 'no_skip' network: its
+    # sign differs between two fp32 summation orders and with it a whole row of that layer's gradient (5e-4)
+    conf, state, m = _variant(VARIANTS[name], seed=23 if name == 'no_skip' else 21)
+    m.train()
+    n = 16
+    rays = synth.make_rays(n, seed=6, random_pose=True)
+    noise = synth.make_noise(conf, n, 128, seed=8)
+    idx = torch.arange(n) % 5
+    st = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in state.items()}
+    ref = mo.render(st, conf, rays, idx, True, True, noise)
+    m._noise = {k: v.cuda() for k, v in noise.items()}
+    out = m({k: v.cuda() for k, v in rays.items()}, idx.cuda(), if_pixel_input=True)
+    for k in ('rgb_values', 'depth_values', 'normal_map', 'weights', 'sdf', 'grad_theta'):
+        assert rel_err(out[k], ref[k]) < 5 * TOL, (k, rel_err(out[k], ref[k]))
+    names = [k for k, v in st.items() if v.requires_grad]
+    g_o = dict(zip(names, torch.autograd.grad(mo.probe_loss(ref), [st[k] for k in names], allow_unused=True)))
+    mo.probe_loss(out).backward()
+    for k, p in m.named_parameters():
+        if g_o.get(k) is not None:
+            assert rel_err(p.grad, g_o[k]) < 5 * TOL, (k, rel_err(p.grad, g_o[k]))
+
+
+def test_wide_positional_encoding_is_refused():
+    """multires = 10 is 63 encoding slots; the kernels hold 48 (multires <= 7; every conf of the reference uses 6)."""
+    with pytest.raises(RuntimeError, match='positional encoding'):
+        _, _, m = _variant(_set('implicit_network', multires=10))
+        m.implicit_network.get_outputs(torch.zeros(64, 3, device='cuda'))
