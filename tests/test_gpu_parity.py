@@ -205,7 +205,8 @@ def test_hash_encoder_kernels():
     g = torch.Generator().manual_seed(13)
     for ic in [dict(num_levels=16, level_dim=2, logmap=19, base_size=16, end_size=2048),
                dict(num_levels=4, level_dim=2, logmap=10, base_size=16, end_size=64),
-               dict(num_levels=6, level_dim=4, logmap=12, base_size=8, end_size=128)]:
+               dict(num_levels=6, level_dim=4, logmap=12, base_size=8, end_size=128),
+               dict(num_levels=3, level_dim=8, logmap=11, base_size=4, end_size=32)]:
         geo = hg.level_geometry(ic)
         B, L, C = 513, geo['L'], geo['C']
         x = torch.rand(B, 3, generator=g)
@@ -280,6 +281,41 @@ def test_hash_encoder_kernels():
             _lib.call('msdf_hash_encode_backward_ws', _lib.ptr(grad_g), _lib.ptr(xg), _lib.ptr(eg), _lib.ptr(offs),
                       _lib.ptr(ge_b), B, 3, C, L, geo['S'], geo['H'], 0, _lib.ptr(dy), None, n_entries,
                       _lib.ptr(ws), nbytes - 1, st)
+
+
+def test_hash_encoder_single_feature_levels():
+    """level_dim = 1 (the reference's kernels are instantiated for 1, 2, 4, 8): forward with dy_dx and the first-order
+    backward, atomic and binned; the second-order kernels need C > 1 in the reference too (hashencoder.cu:431)."""
+    from oracle import hashgrid_oracle as hg
+    from monosdf_amd import _lib
+    g = torch.Generator().manual_seed(17)
+    geo = hg.level_geometry(dict(num_levels=5, level_dim=1, logmap=9, base_size=4, end_size=48))
+    B, L, C = 301, geo['L'], geo['C']
+    x = torch.rand(B, 3, generator=g)
+    emb = torch.rand(geo['n_entries'], C, generator=g) - 0.5
+    out_o, dy_o = hg.encode_forward(x, emb, geo, True)
+    offs = torch.tensor(geo['offsets'], dtype=torch.int32).cuda()
+    xg, eg = x.cuda(), emb.cuda()
+    out, dy = torch.empty(L, B, C, device='cuda'), torch.empty(B, L * 3 * C, device='cuda')
+    st = _lib.stream_ptr()
+    _lib.call('msdf_hash_encode_forward', _lib.ptr(xg), _lib.ptr(eg), _lib.ptr(offs), _lib.ptr(out), B, 3, C, L,
+              geo['S'], geo['H'], 1, _lib.ptr(dy), st)
+    assert rel_err(out, out_o) < 2e-6 and rel_err(dy, dy_o) < 2e-6
+    grad = torch.randn(L, B, C, generator=g)
+    grad_g = grad.cuda()
+    ge_o = hg.encode_backward_grid(grad, x, geo, geo['n_entries'])
+    gi_o = hg.encode_backward_input(grad, dy_o, geo)
+    ge, gi = torch.zeros_like(eg), torch.zeros_like(xg)
+    _lib.call('msdf_hash_encode_backward', _lib.ptr(grad_g), _lib.ptr(xg), _lib.ptr(eg), _lib.ptr(offs), _lib.ptr(ge),
+              B, 3, C, L, geo['S'], geo['H'], 1, _lib.ptr(dy), _lib.ptr(gi), st)
+    assert rel_err(ge, ge_o) < 1e-5 and rel_err(gi, gi_o) < 1e-5
+    n_entries = geo['n_entries']
+    nbytes = _lib.load().msdf_hash_scatter_workspace_bytes(B, C, L, n_entries)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+    ge_b = torch.zeros_like(eg)
+    _lib.call('msdf_hash_encode_backward_ws', _lib.ptr(grad_g), _lib.ptr(xg), _lib.ptr(eg), _lib.ptr(offs),
+              _lib.ptr(ge_b), B, 3, C, L, geo['S'], geo['H'], 0, _lib.ptr(dy), None, n_entries, _lib.ptr(ws), nbytes, st)
+    assert rel_err(ge_b, ge_o) < 1e-5
 
 
 @pytest.mark.parametrize('name', [n for n in ALL_CASES if 'eval' in n and 'image' not in n])
