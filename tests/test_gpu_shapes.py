@@ -228,3 +228,26 @@ def test_hash_grid_model_variants_against_oracle(name):
             # fp32 result is 2e-4 from its fp64 result on this tensor (8 levels x 4 features case)
             bar = 2e-3 if k.endswith('encoding.embeddings') else 5 * TOL
             assert rel_err(p.grad, g_o[k]) < bar, (k, rel_err(p.grad, g_o[k]))
+
+
+@pytest.mark.parametrize('P', [0, 1, 15, 16, 17, 63, 65])
+def test_tiny_and_empty_point_sets(P):
+    """Fewer points than a wave tile (16) / a workgroup (64), and none at all: the public evaluation methods."""
+    from oracle import monosdf_oracle as mo
+    conf, state, m = _build(64, 8, 'fp32')
+    m.eval()
+    g = torch.Generator().manual_seed(P + 1)
+    x = (torch.rand(P, 3, generator=g) * 2 - 1)
+    net = m.implicit_network
+    with torch.no_grad():
+        vals = net.get_sdf_vals(x.cuda())
+    sdf, feat, grad = net.get_outputs(x.cuda())
+    gu = net.gradient_sdf(x.cuda())
+    assert vals.shape == (P, 1) and sdf.shape == (P, 1) and grad.shape == (P, 3) and gu.shape[0] == P
+    assert feat.shape == (P, conf['feature_vector_size'])
+    if P == 0:
+        return
+    st = {k: v.clone() for k, v in state.items()}
+    sdf_o, feat_o, grad_o = mo.get_outputs(st, conf, x, create_graph=False)
+    assert rel_err(sdf, sdf_o) < TOL and rel_err(feat, feat_o) < TOL and rel_err(grad, grad_o) < TOL
+    assert rel_err(vals, mo.get_sdf_vals(st, conf, x)) < TOL
