@@ -65,6 +65,28 @@ __global__ void __launch_bounds__(256) loop_k(const float* __restrict__ in, floa
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 16; ++j) res += c[i][j];
+  } else if (SHAPE == 7) {
+    // 16x16x4 with the A operand re-read from LDS: one ds_read_b128 per 4 MFMAs, two accumulators (the MLP kernels' mix)
+    __shared__ v4f wbuf[64 * 33];
+    for (int i = threadIdx.x; i < 64 * 33; i += 256) wbuf[i] = (v4f){a[0], a[1], a[2], a[3]} * (float)(i & 7);
+    __syncthreads();
+    v4f c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+    const v4f* w = wbuf + (threadIdx.x & 63);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const v4f f0 = w[(2 * k) * 64 + (it & 15) * 64], f1 = w[(2 * k + 1) * 64 + (it & 15) * 64];
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(f0.x, b[0], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(f1.x, b[0], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(f0.y, b[1], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(f1.y, b[1], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(f0.z, b[2], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(f1.z, b[2], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(f0.w, b[3], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(f1.w, b[3], c1, 0, 0, 0);
+      }
+    }
+    res = c0.x + c0.y + c0.z + c0.w + c1.x + c1.y + c1.z + c1.w;
   } else {
     v32f c[2];
 #pragma unroll
@@ -128,6 +150,7 @@ int main() {
     run<5>("1 chain, 1 wave/SIMD", in, out, blocks / 2, iters, cyc, 2.0 * 16 * 16 * 1 * 4, 4);
     run<6>("2 chains, 1 wave/SIMD", in, out, blocks / 2, iters, cyc, 2.0 * 16 * 16 * 1 * 4, 4);
     run<0>("16x16x4, 1 wave/SIMD", in, out, blocks / 2, iters, cyc, 2.0 * 16 * 16 * 4, 8);
+    run<7>("16x16x4 + LDS A reads", in, out, blocks, iters / 2, cyc, 2.0 * 16 * 16 * 4, 16);
   }
   return 0;
 }
