@@ -87,6 +87,28 @@ __global__ void __launch_bounds__(256) loop_k(const float* __restrict__ in, floa
       }
     }
     res = c0.x + c0.y + c0.z + c0.w + c1.x + c1.y + c1.z + c1.w;
+  } else if (SHAPE == 8) {
+    // 32x32x2 with the A operand re-read from LDS: one ds_read_b128 per 4 MFMAs (half the LDS bytes per product)
+    __shared__ v4f wbuf2[64 * 33];
+    for (int i = threadIdx.x; i < 64 * 33; i += 256) wbuf2[i] = (v4f){a[0], a[1], a[2], a[3]} * (float)(i & 7);
+    __syncthreads();
+    v16f c0, c1;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { c0[j] = 0.f; c1[j] = 0.f; }
+    const v4f* w = wbuf2 + (threadIdx.x & 63);
+    for (int it = 0; it < iters; ++it) {
+      const v4f f0 = w[(it & 15) * 64], f1 = w[64 + (it & 15) * 64];
+      c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(f0.x, b[0], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f1.x, b[0], c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(f0.y, b[1], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f1.y, b[1], c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(f0.z, b[2], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f1.z, b[2], c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(f0.w, b[3], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f1.w, b[3], c1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) res += c0[j] + c1[j];
   } else {
     v32f c[2];
 #pragma unroll
@@ -151,6 +173,7 @@ int main() {
     run<6>("2 chains, 1 wave/SIMD", in, out, blocks / 2, iters, cyc, 2.0 * 16 * 16 * 1 * 4, 4);
     run<0>("16x16x4, 1 wave/SIMD", in, out, blocks / 2, iters, cyc, 2.0 * 16 * 16 * 4, 8);
     run<7>("16x16x4 + LDS A reads", in, out, blocks, iters / 2, cyc, 2.0 * 16 * 16 * 4, 16);
+    run<8>("32x32x2 + LDS A reads", in, out, blocks, iters / 2, cyc, 2.0 * 32 * 32 * 2, 8);
   }
   return 0;
 }
