@@ -1,13 +1,19 @@
 """bench.py -- rays/sec of the SDF volume-rendering training step (fwd + loss + bwd + Adam) on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1 without WORLD_SIZE in the environment: this process starts the N ranks itself (python -m
+    torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...) BEFORE any GPU call and exits
+    with their code; under a launcher (WORLD_SIZE set) it is one of the ranks and WORLD_SIZE must equal --gpus.
+    Fewer than N visible devices is an error, never a silent one-GPU run.
 
 Workload = BASELINE.json configs[1]: 1024 rays x 98 samples per GPU, ImplicitNetwork 8x256
 (multires 6, skip [4], weight-norm, geometric init) + RenderingNetwork 289-256-256-3, error-bounded
 sampler 64/128/32; synthetic rays (origins U(-0.2,0.2)^3, unit directions) and random-init weights.
-Weak scaling: every rank renders its own 1024-ray batch, gradients are averaged with one RCCL
-all-reduce of the flat 2.7 MB gradient, as the reference's DDP does.
+Weak scaling: every rank renders its own 1024-ray batch, gradients are averaged over RCCL as the reference's
+DDP does (one flat 2.7 MB all-reduce; with the hash grid the 48.8 MB table gradient travels as a second message
+that starts behind the scatter kernel, parallel.GradientAverager).  For N > 1 the line also carries `multi_gpu`:
+the number of ranks that answered an all-reduce, per-rank ms/step (min / max) and the all-reduce time per step
+(HIP events) for configs[1] and configs[2].
 
 Every step renders a different one of 8 pre-generated ray batches.  Prints ONE JSON line (rank 0):
 `value` = the configs[1] training step at the random-init state (density beta 0.1, the sampler converges in one
@@ -16,11 +22,14 @@ round) on the fp32 MFMA core, with `roofline` (dominant kernel, HIP-event timed 
 BASELINE.md section 3, rank 0, N=1 only).  Beside it, never mixed into `value` (N=1 only):
 `sharp_state` = the same step at density beta 0.01, where the sampler needs 2+ rounds, with the
 rounds per step and what the speculation of the round count cost; `hash_grid` = configs[2] with its HBM roofline;
-`alt_matrix_core` = the bf16x3 core.
+`alt_matrix_core` = the bf16x3 core; `sustained` = 400 consecutive Adam steps from random init, a fresh ray batch
+every step (what training costs once beta moves and the sampler needs more rounds).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -106,22 +115,27 @@ def _cpu_time(n_rays, iters, threads):
 
 def cpu_baseline():
     """the CPU oracle (a port of the reference's PyTorch path, pinned by tests/golden) on
-    the configs[1] workload -- 1024 rays, 3 timed steady-state iterations on all host cores; plus the reference
-    runner's own setting of ONE thread (monosdf_train.py:37) on a bounded sample."""
+    the configs[1] workload.  Three separately labelled figures: `value` = the WHOLE 1024-ray batch, 3 timed
+    steady-state iterations, on the thread count picked by `thread_scan`; `thread_scan` = a QUARTER batch (256 rays,
+    1 timed iteration) on a few thread counts -- smaller tensors fit the caches better, so its rays/s are higher than
+    `value` at the same thread count and are only used to choose; `one_thread` = the reference runner's own setting
+    (monosdf_train.py:37), 192 rays, 2 timed iterations."""
     # "all cores": PyTorch's default thread count can exceed the CPUs this process may use (a GPU box hands 16 of
-    # its 128 to one GPU's job) and then runs slower than fewer threads: take the fastest of a few counts, measured
-    # on a quarter batch, and say which
+    # its 128 to one GPU's job) and then runs slower than fewer threads
     most = torch.get_num_threads()
     tried = {}
     for t in sorted({most, min(most, 64), min(most, 32), min(most, 16)}):
         tried[t] = _cpu_time(N_RAYS // 4, 1, t)
     cores = max(tried, key=tried.get)
     return {'value': _cpu_time(N_RAYS, 3, cores), 'unit': 'rays/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d rays x 98 samples (the whole configs[1] batch), fwd+bwd, 3 timed iterations after 1 warm-up, '
-                      'fp32 PyTorch CPU oracle, sampler k=1; thread count = the fastest of %s on a quarter batch '
-                      '(rays/s: %s)' % (N_RAYS, sorted(tried), {k: round(v, 1) for k, v in sorted(tried.items())}),
-            'one_thread': {'value': _cpu_time(192, 1, 1), 'unit': 'rays/s', 'cores': 1,
-                           'sample': '192 rays x 98 samples, fwd+bwd, 1 timed iteration after 1 warm-up, '
+            'sample': 'FULL batch: %d rays x 98 samples (the whole configs[1] batch), fwd+bwd, 3 timed iterations after '
+                      '1 warm-up, fp32 PyTorch CPU oracle, sampler k=1, %d threads' % (N_RAYS, cores),
+            'thread_scan': {'sample': 'QUARTER batch: %d rays x 98 samples, fwd+bwd, 1 timed iteration after 1 warm-up; '
+                                      'used only to pick the thread count of `value` (a quarter batch runs at more '
+                                      'rays/s than the full one on the same threads)' % (N_RAYS // 4),
+                            'unit': 'rays/s', 'rays_per_s_by_threads': {str(k): round(v, 1) for k, v in sorted(tried.items())}},
+            'one_thread': {'value': _cpu_time(192, 2, 1), 'unit': 'rays/s', 'cores': 1,
+                           'sample': '192 rays x 98 samples, fwd+bwd, 2 timed iterations after 1 warm-up, '
                                      'torch.set_num_threads(1) as the reference runner sets it'}}
 
 
@@ -201,7 +215,7 @@ def grid_report(args, kern, dt, world, rounds, loss, sampler):
     }
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
@@ -214,33 +228,124 @@ def main():
     ap.add_argument('--no-alt-precision', dest='alt_precision', action='store_false',
                     help='skip the measurement on the other matrix core (reported under alt_matrix_core)')
     ap.add_argument('--no-extras', dest='extras', action='store_false',
-                    help='skip sharp_state and hash_grid (profiling runs want the headline workload only)')
+                    help='skip sharp_state, hash_grid and sustained (profiling runs want the headline workload only)')
+    ap.add_argument('--sustained-steps', type=int, default=400,
+                    help='length of the `sustained` run (consecutive Adam steps from random init, fresh rays per step)')
     ap.add_argument('--beta', type=float, default=0.1,
                     help='density beta of the state `value` is measured at (0.1 = random init; profiling runs of the '
                          'sharp state pass 0.01)')
-    args = ap.parse_args()
+    ap.add_argument('--dry-run', action='store_true',
+                    help='launcher / rendezvous check without a GPU: the ranks meet over gloo on the CPU, the kernels '
+                         'are skipped (a step is the flat gradient all-reduce alone), `value` is null')
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    """--gpus N > 1 outside a launcher: start the N ranks as a CHILD process tree (one process per GPU, the
+    reference's launch: training/exp_runner.py:73-77 under torch.distributed.launch) and return its exit code.
+    Nothing here touches the GPU (counting devices does not initialise it), and nothing is exec'ed over this process."""
+    if not args.dry_run:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.stderr.write('bench.py: --gpus %d but only %d GPU(s) visible -- refusing to run fewer ranks\n'
+                             % (args.gpus, have))
+            return 2
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC (RCCL across processes needs it on this host)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+class _StdoutToStderr:
+    """RCCL / gloo may print a banner on stdout when the first communicator is built: stdout is kept for the one
+    JSON line, so file descriptor 1 points at stderr while a process group comes up."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
+def dry_run(args, rank, world):
+    """The rendezvous and the collectives of a step without kernels: gloo on the CPU."""
+    import torch.distributed as dist
+    from monosdf_amd import parallel
+    with _StdoutToStderr():
+        dist.init_process_group(backend='gloo', init_method='env://')
+        count = torch.ones(1)
+        dist.all_reduce(count)
+    try:
+        params = [torch.nn.Parameter(torch.zeros(670395))]           # the 8x256 network's gradient, one message
+        averager = parallel.GradientAverager(params)
+        dist.barrier()
+        t0 = time.time()
+        for i in range(args.steps):
+            params[0].grad = torch.full_like(params[0], float(rank + 1))
+            averager.average()
+        dist.barrier()
+        dt = torch.tensor([time.time() - t0], dtype=torch.float64)
+        every = [torch.zeros_like(dt) for _ in range(world)]
+        dist.all_gather(every, dt)
+        ok = bool(torch.allclose(params[0].grad, torch.full_like(params[0], (world + 1) / 2.0)))
+        if rank == 0:
+            per_rank = [1e3 * float(t) / max(args.steps, 1) for t in every]
+            print(json.dumps({
+                'metric': 'rays/sec fwd+bwd, 1024 rays x 98 samples, 8x256 SDF MLP', 'value': None, 'unit': 'rays/s',
+                'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': max(per_rank),
+                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                'dry_run': True,
+                'config': {'workload': 'dry run: rendezvous + the flat gradient all-reduce of configs[1] over gloo on the '
+                                       'CPU, no kernels'},
+                'multi_gpu': {'backend': 'gloo', 'ranks_answering': int(count.item()), 'gradient_mean_correct': ok,
+                              'per_rank_ms_per_step': {'min': min(per_rank), 'max': max(per_rank)}}}))
+    finally:
+        dist.destroy_process_group()
+    return 0
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus < 1:
+        sys.stderr.write('bench.py: --gpus must be >= 1\n')
+        return 2
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        return launch_ranks(args, argv)
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        sys.stderr.write('bench.py: --gpus %d but the launcher started %d rank(s)\n' % (args.gpus, world))
+        return 2
+    if args.dry_run:
+        return dry_run(args, rank, world)
+    if torch.cuda.device_count() <= local_rank:
+        sys.stderr.write('bench.py: rank %d has no GPU (%d visible)\n' % (rank, torch.cuda.device_count()))
+        return 2
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     use_dist = world > 1 or os.environ.get('MSDF_FORCE_DIST') == '1'    # the env knob exercises RCCL on one GPU
     if use_dist:
         import torch.distributed as dist
-        # RCCL may print a version banner on stdout when the first communicator is built: keep stdout for the one
-        # JSON line (the banner goes to stderr)
-        sys.stdout.flush()
-        saved_stdout = os.dup(1)
-        os.dup2(2, 1)
-        try:
+        with _StdoutToStderr():
             dist.init_process_group(backend='nccl', init_method='env://', device_id=device)
             dist.barrier(device_ids=[local_rank])
             torch.cuda.synchronize()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved_stdout, 1)
-            os.close(saved_stdout)
 
     from monosdf_amd import _lib, ops, parallel
     from monosdf_amd.model.network import MonoSDFNetwork
@@ -250,8 +355,17 @@ def main():
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
-    def measure(precision, grid=False, beta=0.1):
-        """W warm-up + K timed steps of the training step on the given matrix core; returns the max over ranks."""
+    def device_rays(n, gen):
+        """A fresh ray batch drawn on the device (the `sustained` run: one per step, made before the timed region)."""
+        o = (torch.rand(n, 3, device=device, generator=gen) - 0.5) * 0.4
+        d = torch.nn.functional.normalize(torch.randn(n, 3, device=device, generator=gen), dim=1)
+        pose = torch.eye(4, device=device).expand(n, 4, 4).contiguous()
+        return {'ray_dirs': d, 'ray_cam_loc': o, 'ray_dirs_tmp': d.clone(), 'ray_pose': pose}
+
+    def measure(precision, grid=False, beta=0.1, steps=None, fresh=False):
+        """W warm-up + K timed steps of the training step on the given matrix core; returns the max over ranks.
+        fresh: a different ray batch EVERY step (pre-generated on the device) instead of cycling through 8."""
+        steps = args.steps if steps is None else steps
         torch.manual_seed(0)                      # same initial weights on every rank (as DDP would broadcast)
         model = MonoSDFNetwork(model_conf(grid=grid)).to(device).train()
         model.set_precision(precision)
@@ -262,48 +376,73 @@ def main():
             opt = torch.optim.Adam(params, lr=5e-4, fused=True)      # one multi-tensor launch for the whole update
         except (RuntimeError, TypeError):
             opt = torch.optim.Adam(params, lr=5e-4)
-        averager = parallel.GradientAverager(params) if use_dist else None
+        averager = parallel.GradientAverager(params, timing=True) if use_dist else None
         torch.manual_seed(1234 + rank)            # per-rank sampling noise
         # every rank cycles through its own 8 batches (weak scaling: no DistributedSampler in the reference)
-        batches = [make_rays(N_RAYS, 1 + 1000 * rank + b, device) for b in range(N_BATCHES)]
+        if fresh:
+            gen = torch.Generator(device=device)
+            gen.manual_seed(99 + rank)
+            batches = [device_rays(N_RAYS, gen) for _ in range(args.warmup + steps)]
+        else:
+            batches = [make_rays(N_RAYS, 1 + 1000 * rank + b, device) for b in range(N_BATCHES)]
         indices = torch.arange(N_RAYS, device=device)
         smp = model.ray_sampler
         rounds_seen = []
 
         def step(i):
             opt.zero_grad(set_to_none=True)
-            out = model(batches[i % N_BATCHES], indices, if_pixel_input=True)
+            out = model(batches[i % len(batches)], indices, if_pixel_input=True)
             loss = ops.probe_loss(out)        # the BASELINE.md probe loss, value + gradients in one HIP launch
             loss.backward()
             if averager is not None:
-                averager.average()            # one flat RCCL all-reduce of a persistent buffer
+                averager.average()            # RCCL: the flat MLP block here, the table gradient already in flight
             opt.step()
             rounds_seen.append(smp.last_rounds)
             return loss
 
+        first_loss = None
         for i in range(args.warmup):
-            step(i)
+            l0 = step(i)
+            first_loss = first_loss if first_loss is not None else float(l0.item())
         del rounds_seen[:]
         stats0 = dict(smp.stats)
+        if averager is not None:
+            averager.timings = {'flat': [], 'overlapped': []}
         _lib.PROFILE = {}
         _lib.PROFILE_NAMES = TIMED
         barrier()
         t0 = time.time()
-        for i in range(args.steps):
+        for i in range(steps):
             loss = step(args.warmup + i)
         barrier()
-        dt = time.time() - t0
+        dt_own = dt = time.time() - t0
         prof, _lib.PROFILE = _lib.PROFILE, None
+        multi = None
         if use_dist:
-            t = torch.tensor([dt], device=device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            every = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(every, t)
+            per_rank = [1e3 * float(e.item()) / steps for e in every]
+            dt = max(float(e.item()) for e in every)
+            count = torch.ones(1, device=device)
+            dist.all_reduce(count)
+            ar = {k: (float(np.sum([a.elapsed_time(b) for a, b in v])) / steps if v else 0.0)
+                  for k, v in averager.timings.items()}
+            multi = {'rccl_ranks': int(count.item()),
+                     'per_rank_ms_per_step': {'min': min(per_rank), 'max': max(per_rank)},
+                     # HIP events on the stream each message runs on (rank 0): `flat` = the MLP block, after the backward
+                     # pass on the main stream (exposed); `overlapped` = the hash-grid table gradient on the comm stream,
+                     # started behind the scatter kernel, under the weight-gradient kernels
+                     'allreduce_ms_per_step': ar,
+                     'gradient_bytes': {'flat': 4 * (averager.flat.numel() if averager.flat is not None else 0),
+                                        'overlapped': 4 * sum(p.numel() for p in averager.big)}}
+            averager.close()
         # per-entry-point device time (HIP events on the launch stream, inside the timed region)
         kern = {}
         for name, evs in prof.items():
             ms = [a.elapsed_time(b) for a, b in evs]
-            kern[name] = {'launches_per_step': len(ms) / args.steps, 'avg_ms': float(np.mean(ms)),
-                          'ms_per_step': float(np.sum(ms)) / args.steps}
+            kern[name] = {'launches_per_step': len(ms) / steps, 'avg_ms': float(np.mean(ms)),
+                          'ms_per_step': float(np.sum(ms)) / steps}
         plan = model.implicit_network._fused(device).mp.plan
         hist = {}
         for r in rounds_seen:
@@ -315,8 +454,9 @@ def main():
                    # twice), `idle_rounds` = rounds enqueued beyond the ones that ran (one SDF evaluation of 131,072
                    # points each, results unused)
                    'repeated_passes': d['repeats'], 'idle_rounds': d['idle_rounds'], 'beta0': beta + 1e-4}
-        return dict(dt=dt, kern=kern, rounds=hist, sampler=sampler, loss=float(loss.item()), precision=precision,
-                    slots=(plan.hsum, plan.qsum, plan.absum))
+        return dict(dt=dt, dt_own=dt_own, steps=steps, kern=kern, rounds=hist, sampler=sampler, loss=float(loss.item()),
+                    first_loss=first_loss, precision=precision, slots=(plan.hsum, plan.qsum, plan.absum), multi=multi,
+                    beta_end=float(model.density.get_beta().item()))
 
     def mlp_rooflines(m):
         """Roofline of the dominant SDF kernel.  fp32 core: MFMA-bound (algorithmic FLOPs, SURVEY.md 8(d));
@@ -354,7 +494,7 @@ def main():
         return {k: round(v['ms_per_step'], 4) for k, v in sorted(m['kern'].items())}
 
     def rate(m):
-        return world * N_RAYS * args.steps / m['dt']
+        return world * N_RAYS * m['steps'] / m['dt']
 
     grid_only = args.config == 'grid'
     primary = measure(args.precision, grid=grid_only, beta=args.beta)
@@ -362,7 +502,10 @@ def main():
     extras = args.extras and single and not grid_only
     sharp = measure(args.precision, beta=0.01) if extras else None
     alt = measure('bf16x3' if args.precision == 'fp32' else 'fp32') if (extras and args.alt_precision) else None
-    grid = measure('fp32', grid=True) if extras else None
+    # the hash-grid configuration: beside the headline at N = 1, and at N > 1 for its gradient exchange
+    grid = measure('fp32', grid=True) if (extras or (use_dist and args.extras and not grid_only)) else None
+    sustained = measure(args.precision, steps=args.sustained_steps, fresh=True) \
+        if (extras and args.sustained_steps > 0) else None
 
     if rank == 0:
         dtype = 'f32' if args.precision == 'fp32' else 'bf16x3 (fp32 split into 2 bf16, fp32 accumulate)'
@@ -370,10 +513,12 @@ def main():
             res = grid_report(args, primary['kern'], primary['dt'], world, primary['sampler']['mean_rounds'],
                               primary['loss'], primary['sampler'])
             res['dtype'] = dtype
+            if primary['multi'] is not None:
+                res['multi_gpu'] = primary['multi']
             print(json.dumps(res))
             if use_dist:
                 dist.destroy_process_group()
-            return
+            return 0
         mf, hb = mlp_rooflines(primary)
         res = {
             'metric': 'rays/sec fwd+bwd, 1024 rays x 98 samples, 8x256 SDF MLP',
@@ -391,6 +536,11 @@ def main():
             'kernels_ms_per_step': ms(primary),
             'loss': primary['loss'],
         }
+        if primary['multi'] is not None:
+            res['multi_gpu'] = dict(primary['multi'], backend='nccl (RCCL)')
+            if grid is not None:
+                res['multi_gpu']['hash_grid'] = dict(grid['multi'], value=rate(grid), unit='rays/s',
+                                                     ms_per_step=1e3 * grid['dt'] / grid['steps'])
         if sharp is not None:
             smf, shb = mlp_rooflines(sharp)
             res['sharp_state'] = {
@@ -399,7 +549,18 @@ def main():
                 'value': rate(sharp), 'unit': 'rays/s', 'ms_per_step': 1e3 * sharp['dt'] / args.steps,
                 'sampler': sharp['sampler'], 'roofline': smf if args.precision == 'fp32' else (shb or smf),
                 'kernels_ms_per_step': ms(sharp)}
-        if grid is not None:
+        if sustained is not None:
+            res['sustained'] = {
+                'what': '%d consecutive training steps (fwd + loss + bwd + Adam, lr 5e-4) from the random-init state, a '
+                        'FRESH ray batch every step: density beta moves, the sampler starts to need 2+ rounds, the '
+                        'round-count guess misses now and then' % sustained['steps'],
+                'value': rate(sustained), 'unit': 'rays/s', 'steps': sustained['steps'],
+                'ms_per_step': 1e3 * sustained['dt'] / sustained['steps'],
+                'seconds': sustained['dt'], 'sampler': sustained['sampler'],
+                'beta_start': args.beta + 1e-4, 'beta_end': sustained['beta_end'],
+                'loss_first_step': sustained['first_loss'], 'loss_last_step': sustained['loss'],
+                'kernels_ms_per_step': ms(sustained)}
+        if grid is not None and single:
             g = grid_report(args, grid['kern'], grid['dt'], world, grid['sampler']['mean_rounds'], grid['loss'],
                             grid['sampler'])
             res['hash_grid'] = {k: g[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'config', 'roofline',
@@ -420,7 +581,8 @@ def main():
         print(json.dumps(res))
     if use_dist:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

@@ -280,6 +280,11 @@ class ErrorBoundSampler(RaySampler):
             a.extra_idx = extra_idx.data_ptr()
 
         group = self.global_rounds
+        if group is not None and speculate > 0:
+            # one all-reduce is enqueued per enqueued round: the count must be the same on every rank, and a
+            # per-rank guess (each rank's own history of calls) is not -- enqueue all rounds; the ones the global
+            # flags do not ask for are no-ops, and a miss cannot happen
+            speculate = K
         rounds = 0
         with torch.no_grad():
             while True:

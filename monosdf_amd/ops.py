@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from . import _lib, plan as planlib
+from . import _lib, parallel, plan as planlib
 
 
 def _need_cuda(t, name):
@@ -360,17 +360,26 @@ class SdfMlpFunction(torch.autograd.Function):
         if P > 0:
             _lib.call('msdf_sdf_backward', C.byref(plan), C.byref(b), _lib.stream_ptr())
             start_side_work(dev)                 # the colour network's queued weight-gradient launch, if any
+            between = getattr(ctx, 'after_sweeps', None)
+            if between is not None:
+                between(g_aux)                   # consumers of d loss / d aux that should precede the weight gradients
             grad = mlp.run_wgrad(P_pad, {'ws': ws})
         else:
+            between = getattr(ctx, 'after_sweeps', None)
+            if between is not None:
+                between(g_aux)
             grad = torch.zeros(mp.n_w + mp.n_b, device=dev)
         return (None, g_aux, grad[:mp.n_w], grad[mp.n_w:], None, None, None, None, None, None, None, None, None)
 
 
 class _InnerCtx:
-    """Stands in for autograd's ctx when one Function runs another Function's forward / backward inside its own."""
+    """Stands in for autograd's ctx when one Function runs another Function's forward / backward inside its own.
+    The tensors it is given to save are handed to the OUTER ctx.save_for_backward by the caller (autograd's
+    in-place version check then covers them) and put back before the inner backward runs."""
 
     def __init__(self):
         self.saved_tensors = ()
+        self.after_sweeps = None
 
     def save_for_backward(self, *tensors):
         self.saved_tensors = tensors
@@ -424,14 +433,16 @@ class GridSdfFunction(torch.autograd.Function):
         nrm_b = nrm_b + through[ns:]
         ctx.inner, ctx.enc, ctx.k, ctx.n_entries = inner, enc, k, emb.shape[0]
         ctx.offsets = offsets
-        ctx.save_for_backward(x01, dy_dx, r_lbc)
+        ctx.save_for_backward(x01, dy_dx, r_lbc, *inner.saved_tensors)
+        inner.saved_tensors = ()
         return sdf_a, sdf_b, feat, nrm_a, nrm_b
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_sdf, g_sdf_b, g_feat, g_nrm, g_nrm_b):
-        x01, dy_dx, r_lbc = ctx.saved_tensors
+        x01, dy_dx, r_lbc, *inner_saved = ctx.saved_tensors
         inner, (L, Cdim, S, H), k = ctx.inner, ctx.enc, ctx.k
+        inner.saved_tensors = tuple(inner_saved)
         B, D = x01.shape
         dev = x01.device
         ns = inner.n_split
@@ -451,15 +462,32 @@ class GridSdfFunction(torch.autograd.Function):
         g_raux = grad_grad.permute(1, 0, 2).reshape(B, L * Cdim)
         if A != L * Cdim:
             g_raux = torch.nn.functional.pad(g_raux, (0, A - L * Cdim))
-        res = SdfMlpFunction.backward(inner, g_sdf, g_sdf_b, g_feat, g_nrm, g_nrm_b, g_raux.contiguous())
-        g_aux, g_w, g_b = res[1], res[2], res[3]
-        g1 = g_aux[:, :L * Cdim].reshape(B, L, Cdim).permute(1, 0, 2).contiguous()
-        g_emb = torch.zeros(ctx.n_entries, Cdim, device=dev, dtype=torch.float32)
-        nbytes = _lib.load().msdf_hash_scatter_workspace_bytes(B, Cdim, L, ctx.n_entries)
-        ws = torch.empty(int(nbytes), device=dev, dtype=torch.uint8)
-        _lib.call('msdf_hash_encode_backward_fused', _lib.ptr(g1), _lib.ptr(r_lbc), _lib.ptr(x01), _lib.ptr(ctx.offsets),
-                  _lib.ptr(g_emb), B, D, Cdim, L, S, H, _lib.ptr(gg), ctx.n_entries, _lib.ptr(ws), int(nbytes), st)
-        return (None, g_emb, g_w, g_b) + (None,) * 10
+        done = []
+
+        def scatter(g_aux):
+            """Both embedding gradients in ONE binned scatter, launched between the MLP's sweeps and its weight-gradient
+            kernels: the 48.8 MB result is then complete ~2 ms before the node's backward ends, and a multi-GPU run
+            exchanges it under the weight-gradient kernels (parallel.GradientAverager)."""
+            g1 = g_aux[:, :L * Cdim].reshape(B, L, Cdim).permute(1, 0, 2).contiguous()
+            g_emb = torch.zeros(ctx.n_entries, Cdim, device=dev, dtype=torch.float32)
+            nbytes = _lib.load().msdf_hash_scatter_workspace_bytes(B, Cdim, L, ctx.n_entries)
+            ws = torch.empty(int(nbytes), device=dev, dtype=torch.uint8)
+            _lib.call('msdf_hash_encode_backward_fused', _lib.ptr(g1), _lib.ptr(r_lbc), _lib.ptr(x01),
+                      _lib.ptr(ctx.offsets), _lib.ptr(g_emb), B, D, Cdim, L, S, H, _lib.ptr(gg), ctx.n_entries,
+                      _lib.ptr(ws), int(nbytes), st)
+            parallel.mark_grad_ready(g_emb)
+            done.append(g_emb)
+
+        inner.after_sweeps = scatter
+        try:
+            res = SdfMlpFunction.backward(inner, g_sdf, g_sdf_b, g_feat, g_nrm, g_nrm_b, g_raux.contiguous())
+        finally:
+            inner.after_sweeps = None
+            inner.saved_tensors = ()
+        g_w, g_b = res[2], res[3]
+        # the only reference to the table gradient leaves with the return value: autograd then adopts the tensor as
+        # embeddings.grad instead of copying 48.8 MB
+        return (None, done.pop(), g_w, g_b) + (None,) * 10
 
 
 # ---------------------------------------------------------------------------

@@ -67,8 +67,11 @@ def render_image(model, model_input, indices, total_pixels, split_n_pixels=1024,
         width = sum(_WIDTH[k] for k in keys)
         local = torch.cat(rows, 0) if rows else torch.zeros(0, width, device=model_input['uv'].device)
         if world > 1:
-            gathered = parallel.all_gather_rows(local)
+            # every rank knows the deal (chunk c -> rank c mod world), hence every rank's row count: one collective,
+            # no size exchange and no host read
             n_chunk = [ch['uv'].shape[1] for ch in chunks]
+            gathered = parallel.all_gather_rows(
+                local, sizes=[sum(n_chunk[c] for c in range(r, len(chunks), world)) for r in range(world)])
             span, off = {}, 0
             for r in range(world):                       # rank-major order of the gathered rows
                 for c in range(r, len(chunks), world):
@@ -113,7 +116,9 @@ def sdf_volume(sdf_fn, resolution=512, grid_boundary=(-1.1, 1.1), device='cuda',
             return sdf_fn(pts).reshape(-1)
         a, b = parallel.shard_slice(pts.shape[0], rank, world)
         part = sdf_fn(pts[a:b].contiguous()).reshape(-1, 1) if b > a else pts.new_zeros(0, 1)
-        return parallel.all_gather_rows(part).reshape(-1)
+        # the point list of a level is the same on every rank (the mask comes from gathered values), so the cut is too
+        cuts = [parallel.shard_slice(pts.shape[0], r, world) for r in range(world)]
+        return parallel.all_gather_rows(part, sizes=[hi_ - lo_ for lo_, hi_ in cuts]).reshape(-1)
 
     for i in range(N):
         for j in range(N):

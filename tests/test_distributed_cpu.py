@@ -289,3 +289,121 @@ def _averager_worker(rank, world, port, q):
 def test_gradient_averager_fixed_layout_and_persistent_buffer():
     """same layout on every rank even when a gradient is missing on one of them; no per-step buffer."""
     assert all(_run_workers(_averager_worker))
+
+
+class _TableGrad(torch.autograd.Function):
+    """Stands in for ops.GridSdfFunction: hands autograd a freshly allocated table gradient."""
+
+    @staticmethod
+    def forward(ctx, table, scale):
+        ctx.scale, ctx.shape = scale, table.shape
+        return table.sum().reshape(1) * scale
+
+    @staticmethod
+    def backward(ctx, g):
+        out = torch.full(ctx.shape, float(ctx.scale)) * g
+        _TableGrad.last_ptr = out.data_ptr()
+        return out, None
+
+
+def _overlap_worker(rank, world, port, q):
+    _setup(rank, world, port)
+    try:
+        from monosdf_amd import parallel
+        torch.manual_seed(0)
+        table = torch.nn.Parameter(torch.zeros(4096, 2))           # the "large" parameter: its own, early message
+        w = torch.nn.Parameter(torch.randn(6, 3))
+        b = torch.nn.Parameter(torch.randn(6))
+        avg = parallel.GradientAverager([table, w, b], overlap_min_numel=4096)
+        ok = len(avg.big) == 1 and avg.flat.numel() == 24 and parallel._LISTENERS == 1
+        for step in range(3):
+            for p in (table, w, b):
+                p.grad = None
+            fired = len(avg._inflight)
+            loss = _TableGrad.apply(table, float(rank + 1 + step)).sum() + (w.sum() + b.sum()) * (rank + 1)
+            if not (rank == 1 and step == 2):          # one rank skips the table in one step: reduced as zeros
+                loss.backward()
+                ok &= len(avg._inflight) == fired + 1              # the hook started the exchange during backward
+                ok &= table.grad.data_ptr() == _TableGrad.last_ptr  # autograd adopted the tensor, no 48.8 MB copy
+            else:
+                ((w.sum() + b.sum()) * (rank + 1)).backward()
+            avg.average()
+            want = ((1 + step) + (2 + step)) / 2.0 if step < 2 else (1 + step) / 2.0
+            ok &= bool(torch.all(table.grad == want))
+            ok &= bool(torch.all(w.grad == 1.5)) and bool(torch.all(b.grad == 1.5))
+            ok &= w.grad.data_ptr() == avg.flat.data_ptr() and not avg._inflight
+        avg.close()
+        ok &= parallel._LISTENERS == 0
+        res = [None] * world
+        dist.all_gather_object(res, ok)
+        if rank == 0:
+            q.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_averager_two_blocks_table_gradient_leaves_during_backward():
+    """the table gradient is its own message, started from a post-accumulate hook (before
+    average() is called), the MLP block stays one flat message; a rank without a table gradient sends zeros."""
+    assert all(_run_workers(_overlap_worker))
+
+
+def _gather_sizes_worker(rank, world, port, q):
+    _setup(rank, world, port)
+    try:
+        from monosdf_amd import parallel
+        rows = torch.arange(3 * (rank + 2), dtype=torch.float32).reshape(rank + 2, 3) + 100 * rank
+        known = parallel.all_gather_rows(rows, sizes=[2, 3])
+        asked = parallel.all_gather_rows(rows)
+        try:
+            parallel.all_gather_rows(rows, sizes=[5, 5])
+            raised = False
+        except ValueError:
+            raised = True
+        if rank == 0:
+            q.put((known.shape[0], bool(torch.equal(known, asked)), float(known[2, 0]), raised))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_all_gather_rows_with_known_sizes_needs_no_size_exchange():
+    n, same, first_of_rank1, raised = _run_workers(_gather_sizes_worker)
+    assert n == 5 and same and first_of_rank1 == 100.0 and raised
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bench.py --gpus N: the parent starts N ranks (before any GPU call) or fails -- never a silent one-GPU run
+# ---------------------------------------------------------------------------------------------------------------
+def _bench(*argv, env=None):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + list(argv), env=e, capture_output=True,
+                          text=True, timeout=600)
+
+
+@pytest.mark.parametrize('n', [2, 3])
+def test_bench_launcher_starts_n_ranks(n):
+    import json
+    r = _bench('--gpus', str(n), '--steps', '2', '--dry-run')
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout                     # ONE JSON line, nothing else on stdout
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == n and line['dry_run'] is True and line['value'] is None
+    assert line['multi_gpu']['ranks_answering'] == n and line['multi_gpu']['gradient_mean_correct']
+
+
+def test_bench_launcher_refuses_fewer_devices_than_ranks():
+    """No GPU in this container: --gpus 2 without --dry-run must fail, not run one rank and print n_gpus 1."""
+    if torch.cuda.device_count() >= 2:
+        pytest.skip('two GPUs visible')
+    r = _bench('--gpus', '2', '--steps', '1')
+    assert r.returncode != 0 and 'GPU(s) visible' in r.stderr and r.stdout.strip() == ''
+
+
+def test_bench_refuses_world_size_mismatch():
+    r = _bench('--gpus', '4', '--steps', '1', '--dry-run', env={'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0'})
+    assert r.returncode != 0 and 'launcher started 1 rank' in r.stderr and r.stdout.strip() == ''

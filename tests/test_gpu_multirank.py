@@ -89,6 +89,38 @@ def _worker(rank, world, port, q):
             vol = list(render.sdf_volume(fn, resolution=128, grid_boundary=(-1.1, 1.1), shard=True))[0][2]
             vol1 = list(render.sdf_volume(fn, resolution=128, grid_boundary=(-1.1, 1.1), shard=False))[0][2]
         res['volume_equal'] = bool((vol == vol1).all())
+        # 4. training step of the hash-grid model, every rank on its own half of the rays: the table gradient leaves as
+        # its own message from the post-accumulate hook (behind the scatter, before the weight-gradient kernels), the
+        # MLP block as one flat message; the result is the mean of the two ranks' single-process gradients
+        cg = Case('grid_small_train')
+        mg = build(cg).train()
+        ng = cg.inputs['ray_dirs'].shape[0]
+        half = ng // 2
+
+        def grads_of(lo_, hi_):
+            for p_ in mg.parameters():
+                p_.grad = None
+            mg._noise = None
+            torch.manual_seed(7)
+            o = mg({k: v[lo_:hi_].cuda() for k, v in cg.inputs.items()}, cg.indices[lo_:hi_].cuda(), if_pixel_input=True)
+            loss_ = o['rgb_values'].sum() + o['normal_map'].sum() + 0.1 * (o['grad_theta'].norm(dim=1) - 1).pow(2).sum()
+            loss_.backward()
+        named = [(n_, p_) for n_, p_ in mg.named_parameters() if p_.requires_grad]
+        # without a listening averager: this rank's own gradients of both halves -> the expected mean
+        want = {}
+        for part, (lo_, hi_) in enumerate(((0, half), (half, 2 * half))):
+            grads_of(lo_, hi_)
+            for n_, p_ in named:
+                want[n_] = want.get(n_, 0) + p_.grad.detach().clone() / 2
+        avg = parallel.GradientAverager([p_ for _, p_ in named], overlap_min_numel=1024, timing=True)
+        res['avg_big'] = [n_ for n_, p_ in named if any(p_ is b_ for b_ in avg.big)]
+        grads_of(rank * half, (rank + 1) * half)
+        res['avg_started_in_backward'] = len(avg._inflight)
+        avg.average()
+        torch.cuda.synchronize()
+        res['avg_err'] = max(float((p_.grad - want[n_]).abs().max() / (want[n_].abs().max() + 1e-20)) for n_, p_ in named)
+        res['avg_overlapped_ms'] = [a_.elapsed_time(b_) for a_, b_ in avg.timings['overlapped']]
+        avg.close()
         # plain numpy in the queue: a tensor would travel as a shared-memory handle that dies with this process
         def plain(v):
             if torch.is_tensor(v):
@@ -132,5 +164,8 @@ def test_two_ranks_on_one_gpu():
         for k in res['image']:
             assert np.array_equal(res['image'][k], res['image_single'][k]), k
         assert res['volume_equal']
+        assert res['avg_big'] == ['implicit_network.encoding.embeddings']
+        assert res['avg_started_in_backward'] == 1 and len(res['avg_overlapped_ms']) == 1
+        assert res['avg_err'] < 2e-6, res['avg_err']
     # left alone, the second shard stops after its own 3 rounds (what makes the all-reduce necessary)
     assert sorted(r['rounds']['sync_alone'] for r in allres) == [3, 5]
