@@ -78,7 +78,7 @@ CASES = {
     'mlp_w64_train_k4': dict(kind='mlp', width=64, n_rays=6, jitter=0.05, beta=0.0005, sdf_scale=0.25,
                              training=True, grads=True, trace=True),
     'mlp_w64_train_k5nc': dict(kind='mlp', width=64, n_rays=6, jitter=0.3, beta=0.001, sdf_scale=0.25,
-                               training=True, grads=True),
+                               training=True, grads=True, trace=True),
     'mlp_w64_eval_k2_trace': dict(kind='mlp', width=64, n_rays=6, jitter=0.0, beta=0.01, training=False, trace=True),
     'mlp_w64_train': dict(kind='mlp', width=64, n_rays=24, jitter=0.3, training=True, grads=True),
     'mlp_w64_train_sharp': dict(kind='mlp', width=64, n_rays=16, jitter=0.1, beta=0.01, training=True, grads=True),
@@ -89,7 +89,8 @@ CASES = {
                                per_image_code=True),
     # if_hdr = True (6 of the reference's confs): ReLU instead of the sigmoid on the colour output
     'mlp_w64_hdr_train': dict(kind='mlp', width=64, n_rays=12, jitter=0.3, training=True, grads=True, if_hdr=True),
-    'mlp_w64_hdr_eval': dict(kind='mlp', width=64, n_rays=12, jitter=0.3, training=False, if_hdr=True, ray_seed=4),
+    'mlp_w64_hdr_eval': dict(kind='mlp', width=64, n_rays=12, jitter=0.3, training=False, if_hdr=True, ray_seed=4,
+                             trace=True),
     'mlp_w64_nerf_train': dict(kind='mlp', width=64, n_rays=12, jitter=0.3, training=True, grads=True,
                                render_mode='nerf'),
     'gridless_w128_train': dict(kind='gridless', width=128, n_rays=8, jitter=0.3, training=True, grads='digest'),
@@ -104,6 +105,10 @@ CASES = {
                                 ray_seed=9),
     # the reference's full grid configuration (16 levels, 2^19 entries per hashed level, scannetGrids.conf)
     'grid_full_eval': dict(kind='grid', width=256, n_rays=8, jitter=0.3, training=False, ray_seed=5),
+    # ... and a TRAINING step of it (BASELINE.json configs[2] at 32 rays): every parameter gradient as a digest, the
+    # 12.2 M-float table gradient included -- the reference's double-backward wiring (hashgrid.py:71-101) at hashed
+    # levels and the full table size, over the restated kernels
+    'grid_full_train': dict(kind='grid', width=256, n_rays=32, jitter=0.3, training=True, grads='digest', ray_seed=6),
 }
 
 
@@ -158,6 +163,11 @@ def run_case(name, spec):
                 continue
             rec[('gdig.' if spec['grads'] == 'digest' else 'grad.') + n] = \
                 digest(g) if spec['grads'] == 'digest' else g.numpy()
+            if spec['grads'] == 'digest' and g.numel() > 1000000 and n.endswith('encoding.embeddings'):
+                # the 12.2 M-float table gradient: a fingerprint that sees where every contribution landed
+                offsets = model.implicit_network.encoding.offsets
+                for k, v in synth.table_fingerprint(g, offsets).items():
+                    rec['gtab.%s.%s' % (n, k)] = v
     return rec
 
 

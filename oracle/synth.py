@@ -188,3 +188,20 @@ def analytic_targets(rays, radius=0.6):
     f = lambda a: a.float()[None]
     return {'rgb': f(rgb), 'depth': f((depth / 50.0).unsqueeze(-1)), 'normal': f(n_cam),
             'mask': torch.ones(1, o.shape[0], 1)}
+
+
+def table_fingerprint(grad, offsets, n_proj=4, n_top=64, seed=2024):
+    """Fingerprint of a hash-grid table gradient [n_entries, C] that is too large to commit (48.8 MB) and too sparse
+    for a 16-entry sample to say anything: per-level sum of |g| and of g^2 (which LEVELS received what), projections
+    onto fixed +-1 vectors (every entry's position counts: a contribution scattered to a wrong entry changes them),
+    and the n_top largest entries with their indices.  Everything in float64."""
+    g = np.asarray(grad.detach().cpu().double().numpy() if torch.is_tensor(grad) else grad, dtype=np.float64)
+    off = [int(o) for o in np.asarray(offsets).reshape(-1)]
+    level_abs = np.array([np.abs(g[a:b]).sum() for a, b in zip(off[:-1], off[1:])])
+    level_sq = np.array([(g[a:b] ** 2).sum() for a, b in zip(off[:-1], off[1:])])
+    rng = np.random.default_rng(seed)
+    flat = g.reshape(-1)
+    proj = np.array([(flat * (rng.integers(0, 2, size=flat.size, dtype=np.int8) * 2 - 1)).sum() for _ in range(n_proj)])
+    top = np.argsort(-np.abs(flat), kind='stable')[:n_top]
+    return {'level_abs': level_abs, 'level_sq': level_sq, 'proj': proj, 'top_idx': top.astype(np.int64),
+            'top_val': flat[top]}

@@ -47,6 +47,11 @@ class Case:
         pick = lambda p: {k[len(p):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(p)}
         self.inputs, self.noise, self.out = pick('in.'), pick('noise.'), pick('out.')
         self.grads, self.gdig = pick('grad.'), pick('gdig.')
+        # fingerprints of table gradients too large to commit (synth.table_fingerprint): {param: {field: array}}
+        self.gtab = {}
+        for k, v in pick('gtab.').items():
+            n, field = k.rsplit('.', 1)
+            self.gtab.setdefault(n, {})[field] = v
         self.loss = float(z['loss']) if 'loss' in z.files else None
         self.converged = bool(z['converged']) if 'converged' in z.files else None
         # per-round intermediates recorded inside the reference's sampler (cases generated with trace=True)

@@ -112,7 +112,7 @@ def _worker(rank, world, port, q):
             grads_of(lo_, hi_)
             for n_, p_ in named:
                 want[n_] = want.get(n_, 0) + p_.grad.detach().clone() / 2
-        avg = parallel.GradientAverager([p_ for _, p_ in named], overlap_min_numel=1024, timing=True)
+        avg = parallel.GradientAverager([p_ for _, p_ in named], overlap_min_numel=8000, timing=True)
         res['avg_big'] = [n_ for n_, p_ in named if any(p_ is b_ for b_ in avg.big)]
         grads_of(rank * half, (rank + 1) * half)
         res['avg_started_in_backward'] = len(avg._inflight)

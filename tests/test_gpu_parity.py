@@ -363,6 +363,21 @@ def test_full_gradients_against_golden(name, precision, errlog):
     for n, ref in c.gdig.items():
         d = digest(params[n].grad)
         check(errlog, test, name, n + '(digest)', abs(d[0] - ref[0]).item() / (ref[1].item() + 1e-9))
+    for n, ref in c.gtab.items():
+        # table gradient at the full table size (16 levels, 2^19 entries per hashed level): which level received what,
+        # where every contribution landed (+-1 projections), and the largest entries by index
+        from oracle import synth
+        got = synth.table_fingerprint(params[n].grad, c.state[n.replace('embeddings', 'offsets')].numpy())
+        rms = float(np.sqrt(ref['level_sq'].double().sum()))
+        check(errlog, test, name, n + '(level |g|)',
+              float(np.abs(got['level_abs'] - ref['level_abs'].numpy()).max() / ref['level_abs'].max()))
+        check(errlog, test, name, n + '(level g^2)',
+              float(np.abs(got['level_sq'] - ref['level_sq'].numpy()).max() / ref['level_sq'].max()))
+        check(errlog, test, name, n + '(projections)', float(np.abs(got['proj'] - ref['proj'].numpy()).max() / rms))
+        flat = params[n].grad.detach().reshape(-1).cpu().double().numpy()
+        top = ref['top_idx'].numpy()
+        check(errlog, test, name, n + '(largest entries)',
+              float(np.abs(flat[top] - ref['top_val'].numpy()).max() / np.abs(ref['top_val'].numpy()).max()))
 
 
 def test_full_image_render_chunked(errlog):

@@ -15,7 +15,8 @@ from helpers import Case, rel_err
 
 pytestmark = pytest.mark.gpu
 
-TRACED = ['mlp_w64_eval_k2_trace', 'mlp_w64_eval_k4', 'mlp_w64_eval_k5', 'mlp_w64_eval_k5nc', 'mlp_w64_train_k4']
+TRACED = ['mlp_w64_eval_k2_trace', 'mlp_w64_eval_k4', 'mlp_w64_eval_k5', 'mlp_w64_eval_k5nc', 'mlp_w64_train_k4',
+          'mlp_w64_hdr_eval', 'mlp_w64_train_k5nc']
 
 # measured maxima (profiles/r02_parity_errors.md) x2, absolute unless noted
 TOL_DSTAR = 2e-6        # d* of an interval (values up to ~1)

@@ -41,6 +41,12 @@ def test_forward_and_grads_match_reference(name):
                 scale = ref[1] / max(1, g.numel()) + 1e-12       # mean |g|
                 assert abs(d[0] - ref[0]) < 5e-4 * ref[1] + 1e-9, n
                 assert ((d[3:] - ref[3:]).abs().max() < 5e-2 * scale * 16 + 5e-4 * ref[3:].abs().max()), n
+            if n in c.gtab:
+                from oracle import synth
+                got, ref = synth.table_fingerprint(g, c.state[n.replace('embeddings', 'offsets')].numpy()), c.gtab[n]
+                for k in ('level_abs', 'level_sq', 'proj', 'top_val'):
+                    assert np.abs(got[k] - ref[k].numpy()).max() <= 1e-5 * np.abs(ref[k].numpy()).max(), (n, k)
+                assert np.array_equal(got['top_idx'], ref['top_idx'].numpy()), n
 
 
 def test_sampler_round_counts():
