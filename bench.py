@@ -45,7 +45,7 @@ N_BATCHES = 8          # ray batches cycled through by the timed steps
 TIMED = {'msdf_sdf_forward_if', 'msdf_sdf_fwd_grad', 'msdf_sdf_backward', 'msdf_wgrad', 'msdf_reduce',
          'msdf_color_forward', 'msdf_color_backward', 'msdf_hash_encode_forward', 'msdf_hash_encode_backward',
          'msdf_hash_encode_second_backward', 'msdf_hash_encode_backward_ws', 'msdf_hash_encode_second_backward_ws',
-         'msdf_hash_encode_backward_fused'}
+         'msdf_hash_encode_backward_fused', 'msdf_hash_encode_backward_fused_out'}
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 
 
@@ -153,15 +153,14 @@ def pmc_traffic(entry, precision):
 
 
 def pmc_traffic_grid(entry):
-    """HBM bytes per call of a hash entry point = the sum over its kernels (profiles/r02_pmc_grid.json; FETCH_SIZE x2 +
+    """HBM bytes per call of a hash entry point = the sum over its kernels (profiles/r03_pmc_grid.json; FETCH_SIZE x2 +
     WRITE_SIZE; the x2 of MI355X_MICROARCH.md is calibrated for wide streaming reads, not for 8-byte gathers: the
     forward kernel's figure is an upper bound)."""
     kernels = {'msdf_hash_encode_forward': ['void hg_forward_kernel'],
                'msdf_hash_encode_backward': ['void hg_backward_input_kernel'],
                'msdf_hash_encode_second_backward_ws': ['void hg_second_backward_grad_kernel'],
-               'msdf_hash_encode_backward_fused': ['hb_setup_k', 'void hb_count_k', 'hb_scan_k', 'void hb_place_k',
-                                                   'void hb_accumulate_k']}
-    path = os.path.join(ROOT, 'profiles', 'r02_pmc_grid.json')
+               'msdf_hash_encode_backward_fused_out': ['void hb2_place_k', 'void hb2_accumulate_k']}
+    path = os.path.join(ROOT, 'profiles', 'r03_pmc_grid.json')
     if not os.path.exists(path) or entry not in kernels:
         return None, None
     table = json.load(open(path))
@@ -171,7 +170,7 @@ def pmc_traffic_grid(entry):
         if row is None or 'hbm_bytes_per_launch_corrected' not in row:
             return None, None
         tot += row['hbm_bytes_per_launch_corrected']
-    return tot, 'profiles/r02_pmc_grid.json'
+    return tot, 'profiles/r03_pmc_grid.json'
 
 
 def grid_report(args, kern, dt, world, rounds, loss, sampler):
@@ -188,8 +187,10 @@ def grid_report(args, kern, dt, world, rounds, loss, sampler):
         'msdf_hash_encode_backward_ws': 524.0 * P_main,
         'msdf_hash_encode_second_backward_ws': 524.0 * P_main,
         'msdf_hash_encode_backward_fused': (1164.0 + 1176.0) * P_main,
+        'msdf_hash_encode_backward_fused_out': (1164.0 + 1176.0) * P_main,
     }
-    if 'msdf_hash_encode_backward_fused' in kern:      # there the plain entry point computes d/dx only
+    if 'msdf_hash_encode_backward_fused' in kern or 'msdf_hash_encode_backward_fused_out' in kern:
+        # there the plain entry point computes d/dx only
         per_step_bytes['msdf_hash_encode_backward'] = 524.0 * P_main
     rows = {}
     for n, b in per_step_bytes.items():

@@ -49,7 +49,7 @@ extern "C" {
 #define MSDF_ERR_LAUNCH 2
 #define MSDF_ERR_UNSUPPORTED 3
 
-#define MSDF_ABI_VERSION 4
+#define MSDF_ABI_VERSION 5
 int msdf_abi_version(void);
 
 /* ---- hash grid (reference: hashencoder/src/hashencoder.h:13-15) ----
@@ -91,6 +91,13 @@ int msdf_hash_encode_backward_fused(const float* grad_first, const float* grad_s
                                     const int* offsets, float* grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
                                     uint32_t L, float S, uint32_t H, const float* grad_grad_inputs,
                                     uint64_t n_entries, void* workspace, uint64_t workspace_bytes, void* stream);
+/* The same with "=" instead of "+=": grad_embeddings is an output and need not be initialised by the caller (the
+ * reference's callers zero-fill it first, hashgrid.py:75-76,93-94: here neither that fill nor a read of the table
+ * is needed). */
+int msdf_hash_encode_backward_fused_out(const float* grad_first, const float* grad_second, const float* inputs,
+                                        const int* offsets, float* grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
+                                        uint32_t L, float S, uint32_t H, const float* grad_grad_inputs,
+                                        uint64_t n_entries, void* workspace, uint64_t workspace_bytes, void* stream);
 
 /* ---- fused MLPs ----
  * Every entry point that takes a plan runs on the matrix core named by plan->precision (monosdf_plan.h):

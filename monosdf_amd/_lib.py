@@ -146,6 +146,8 @@ _SIGNATURES = {
                                             C.c_uint64, _P],
     'msdf_hash_encode_backward_fused': [_P, _P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                         C.c_float, C.c_uint32, _P, C.c_uint64, _P, C.c_uint64, _P],
+    'msdf_hash_encode_backward_fused_out': [_P, _P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                            C.c_float, C.c_uint32, _P, C.c_uint64, _P, C.c_uint64, _P],
     'msdf_weightnorm_forward': [_P, _P, C.c_int, _P, _P, _P, _P],
     'msdf_weightnorm_backward': [_P, _P, C.c_int, _P, _P, _P, _P, _P],
     'msdf_pack_weights': [C.POINTER(Plan), _P, _P, _P, _P, _P, _P, _P],
@@ -171,7 +173,7 @@ _SIGNATURES = {
     'msdf_laplace_density_backward': [_P, _P, C.c_int, C.c_int64, C.c_int, _P, _P, _P, _P],
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 

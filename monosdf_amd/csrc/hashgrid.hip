@@ -12,6 +12,7 @@
 // Layouts are the reference's: inputs [B,3] in [0,1], embeddings [n,C], offsets int32 [L+1],
 // outputs [L,B,C], dy_dx [B, L*3*C].  fp32 only (the reference's fp16 path is dead code).
 #include "common.h"
+#include <cstdlib>
 
 #define HG_THREADS 256
 
@@ -40,10 +41,16 @@ struct HgCell {
   bool oob;
 };
 
-// per-level constants (scale, resolution, table size): uniform over a workgroup of the level-major launches
+// per-level constants (scale, resolution, table size): uniform over a workgroup of the level-major launches.
+// The index form of cu:54-72 is decided here, once per level instead of once per corner: `dense` = the running
+// stride never exceeds the table (index = x + y res + z res^2), otherwise the xor hash; `mask` = hsize - 1 when
+// the table size is a power of two (every hashed level of the reference's configurations: the modulo becomes an
+// AND instead of a ~40-instruction integer division per corner).
 struct HgLevel {
   float scale;
   uint32_t res, hsize;
+  uint32_t s1, s2, mask;
+  bool dense;
 };
 __device__ __forceinline__ HgLevel hg_level(const int* __restrict__ offsets, const uint32_t level, const float S,
                                             const uint32_t H) {
@@ -53,7 +60,25 @@ __device__ __forceinline__ HgLevel hg_level(const int* __restrict__ offsets, con
   // fine-level sample by 1e-4 of a cell)
   v.scale = (float)exp2((double)((float)level * S)) * (float)H - 1.0f;
   v.res = (uint32_t)ceilf(v.scale) + 1u;
+  // the loop of hg_index with the coordinates left out: which strides are taken, and whether the last one fits
+  uint32_t stride = 1;
+  v.s1 = v.s2 = 0;
+  if (stride <= v.hsize) stride *= v.res;                        // d = 0 (stride 1)
+  if (stride <= v.hsize) { v.s1 = stride; stride *= v.res; }     // d = 1
+  if (stride <= v.hsize) { v.s2 = stride; stride *= v.res; }     // d = 2
+  v.dense = !(stride > v.hsize);
+  v.mask = ((v.hsize & (v.hsize - 1u)) == 0u) ? v.hsize - 1u : 0u;
   return v;
+}
+
+// hg_index with the level's decisions taken from HgLevel (same value for every input)
+__device__ __forceinline__ uint32_t hg_index_lv(const HgLevel& lv, const uint32_t px, const uint32_t py,
+                                                const uint32_t pz) {
+  uint32_t index;
+  if (lv.dense) index = px + py * lv.s1 + pz * lv.s2;
+  else index = px ^ (py * 2654435761u) ^ (pz * 805459861u);
+  if (lv.mask) return index & lv.mask;
+  return (index < lv.hsize) ? index : index % lv.hsize;
 }
 
 __device__ __forceinline__ HgCell hg_locate(const float* __restrict__ inputs, const HgLevel& lv, const uint32_t b) {
@@ -81,20 +106,19 @@ __device__ __forceinline__ HgCell hg_locate(const float* __restrict__ inputs, co
 // ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
+// one (point, level): the 8 corner reads feed the output and its three directional derivatives
 template <int C>
-__global__ void __launch_bounds__(HG_THREADS)
-hg_forward_kernel(const float* __restrict__ inputs, const float* __restrict__ grid, const int* __restrict__ offsets,
-                  float* __restrict__ outputs, const uint32_t B, const uint32_t L, const float S, const uint32_t H,
-                  const int calc_grad_inputs, float* __restrict__ dy_dx) {
-  const uint32_t b = blockIdx.x * HG_THREADS + threadIdx.x;
-  if (b >= B) return;
-  const uint32_t level = blockIdx.y;
+__device__ __forceinline__ void hg_forward_point(const float* __restrict__ inputs, const float* __restrict__ grid,
+                                                 const int* __restrict__ offsets, float* __restrict__ outputs,
+                                                 const uint32_t B, const uint32_t L, const HgLevel& lv,
+                                                 const uint32_t level, const uint32_t b, const int calc_grad_inputs,
+                                                 float* __restrict__ dy_dx) {
   float* out = outputs + ((size_t)level * B + b) * C;
   // calc_grad_inputs == 2: dy_dx level-major [L, B, 3 C] (a wave writes 64 x 3 C contiguous floats) instead of the
   // reference's [B, L, 3 C] (3 C floats every L 3 C: partial lines written by 16 different launches' blocks)
   float* dy = (calc_grad_inputs == 2) ? dy_dx + ((size_t)level * B + b) * 3 * C
                                       : dy_dx + (size_t)b * 3 * L * C + (size_t)level * 3 * C;
-  const HgCell c = hg_locate(inputs, offsets, b, level, S, H);
+  const HgCell c = hg_locate(inputs, lv, b);
   if (c.oob) {
 #pragma unroll
     for (int ch = 0; ch < C; ++ch) out[ch] = 0.f;
@@ -109,7 +133,7 @@ hg_forward_kernel(const float* __restrict__ inputs, const float* __restrict__ gr
   float v[8][C];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    const uint32_t idx = hg_index(c.gx + (k & 1), c.gy + ((k >> 1) & 1), c.gz + ((k >> 2) & 1), c.hsize, c.res);
+    const uint32_t idx = hg_index_lv(lv, c.gx + (k & 1), c.gy + ((k >> 1) & 1), c.gz + ((k >> 2) & 1));
 #pragma unroll
     for (int ch = 0; ch < C; ++ch) v[k][ch] = table[(size_t)idx * C + ch];
   }
@@ -142,6 +166,18 @@ hg_forward_kernel(const float* __restrict__ inputs, const float* __restrict__ gr
       dy[2 * C + ch] = gz;
     }
   }
+}
+
+template <int C>
+__global__ void __launch_bounds__(HG_THREADS)
+hg_forward_kernel(const float* __restrict__ inputs, const float* __restrict__ grid, const int* __restrict__ offsets,
+                  float* __restrict__ outputs, const uint32_t B, const uint32_t L, const float S, const uint32_t H,
+                  const int calc_grad_inputs, float* __restrict__ dy_dx) {
+  const uint32_t b = blockIdx.x * HG_THREADS + threadIdx.x;
+  if (b >= B) return;
+  const uint32_t level = blockIdx.y;
+  const HgLevel lv = hg_level(offsets, level, S, H);
+  hg_forward_point<C>(inputs, grid, offsets, outputs, B, L, lv, level, b, calc_grad_inputs, dy_dx);
 }
 
 // ---------------------------------------------------------------------------
@@ -636,15 +672,348 @@ hb_accumulate_k(const int* __restrict__ ws, const HbLayout y, float* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------
+// Binned scatter, second form ("hb2", round 3): no counting pass, no scan kernel, no global cursors.
+//
+//   hb2_place_k       a workgroup takes 1,024 consecutive points of one level and owns a FIXED region of 8,192
+//                     records: it counting-sorts its own corner contributions by table slice in LDS, writes them to
+//                     its region in slice order and writes the (slices + 1) run offsets of the region to a run table
+//                     [level][workgroup][slice].  Consecutive points that sit in the same cell (consecutive samples of
+//                     a ray at the coarse levels) are summed on the way -- a segmented reduction over 16-lane rows with
+//                     DPP -- so that one record leaves per run, not per point: fewer records, and the LDS adds of the
+//                     second kernel rarely meet.
+//   hb2_accumulate_k  one workgroup per (level, slice, group of place workgroups): reads the group's runs for its
+//                     slice through the run table, adds them into an LDS accumulator with compare-and-swap float
+//                     adds (both channels of an entry in one 64-bit swap; ds_add_f32 costs ~170 cycles per
+//                     wave-instruction on gfx950, the swap loop ~25) and adds the slice to the table once.
+// What the first form paid for exact bin sizes (hb_setup_k + hb_count_k + hb_scan_k, ~45 us of 255 at B = 104,448)
+// is gone: the work list is a function of the level sizes alone.  Levels with few slices are cut by place workgroups
+// instead (a coarse level of one slice becomes n_wg work items of one run each).
+// ---------------------------------------------------------------------------
+#define HB2_NS_MAX 8192               // slices per level the place kernel's LDS histogram is sized for
+#define HB2_TILE 256                  // runs per pass of the accumulate kernel
+
+struct Hb2Layout {
+  int n_wg, ns_bound, rt_stride, work_max;
+  size_t rec_off_bytes, total_bytes;
+};
+static Hb2Layout hb2_layout(const uint32_t B, const uint32_t C, const uint32_t L, const uint64_t n_entries) {
+  Hb2Layout y;
+  y.n_wg = (int)((B + HB_PTS * HB_THREADS - 1) / (HB_PTS * HB_THREADS));
+  const uint64_t ns = (n_entries * C + HB_SLICE_FLOATS - 1) / HB_SLICE_FLOATS + 1;   // >= slices of any one level
+  y.ns_bound = (int)(ns < (uint64_t)(1 << 30) ? ns : (uint64_t)(1 << 30));
+  y.rt_stride = y.ns_bound + 1;
+  // items of a level: slices x ceil(n_wg / min(slices, n_wg)) <= slices + n_wg
+  y.work_max = (int)((n_entries * C + HB_SLICE_FLOATS - 1) / HB_SLICE_FLOATS + L) + (int)L * y.n_wg;
+  y.rec_off_bytes = (((size_t)L * y.n_wg * y.rt_stride * 4) + 255) & ~(size_t)255;
+  y.total_bytes = y.rec_off_bytes + (size_t)L * y.n_wg * (8 * HB_PTS * HB_THREADS) * (4 + 4 * C);
+  return y;
+}
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(const uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+#define DPP_ROW_SHL(n) (0x100 + (n))       // lane i reads lane i + n of its 16-lane row (0 past the row's end)
+#define DPP_ROW_SHR(n) (0x110 + (n))       // lane i reads lane i - n
+
+// v_i += v_{i+d} where lane i + d continues lane i's run (m = 1.0f) -- four steps sum a run into its first lane
+template <int CN>
+__device__ __forceinline__ void run_sum(float (&v)[CN], const float m1, const float m2, const float m4, const float m8) {
+#pragma unroll
+  for (int ch = 0; ch < CN; ++ch) {
+    v[ch] = __builtin_fmaf(m1, __uint_as_float(dpp_u32<DPP_ROW_SHL(1)>(__float_as_uint(v[ch]))), v[ch]);
+    v[ch] = __builtin_fmaf(m2, __uint_as_float(dpp_u32<DPP_ROW_SHL(2)>(__float_as_uint(v[ch]))), v[ch]);
+    v[ch] = __builtin_fmaf(m4, __uint_as_float(dpp_u32<DPP_ROW_SHL(4)>(__float_as_uint(v[ch]))), v[ch]);
+    v[ch] = __builtin_fmaf(m8, __uint_as_float(dpp_u32<DPP_ROW_SHL(8)>(__float_as_uint(v[ch]))), v[ch]);
+  }
+}
+
+template <int C, int MODE>
+__global__ void __launch_bounds__(HB_THREADS)
+hb2_place_k(const float* __restrict__ grad, const float* __restrict__ grad2, const float* __restrict__ inputs,
+            const int* __restrict__ offsets, const float* __restrict__ gg_inputs, int* __restrict__ ws,
+            const Hb2Layout y, const uint32_t B, const float S, const uint32_t H, float* __restrict__ zero_grid) {
+  extern __shared__ int hb2_lds[];
+  int* hist = hb2_lds;                       // [ns]: counts, then run starts
+  int* part = hb2_lds + y.ns_bound + 1;      // [HB_THREADS] scan scratch
+  const uint32_t level = blockIdx.y;
+  const HgLevel lv = hg_level(offsets, level, S, H);
+  constexpr uint32_t epb = HB_SLICE_FLOATS / C;
+  const int ns = (int)((lv.hsize + epb - 1) / epb);
+  const int tid = threadIdx.x;
+  const uint32_t lane = tid & 63;
+  for (int i = tid; i < ns; i += HB_THREADS) hist[i] = 0;
+  if (zero_grid != nullptr && ns < y.n_wg) {
+    // "=" instead of "+=" (msdf_hash_encode_backward_fused_out): the slices of this level are shared by several
+    // accumulate workgroups, which add with atomics -- the level is zeroed here, one share per place workgroup
+    // (this kernel has finished before the accumulate kernel starts)
+    const uint32_t nfl = lv.hsize * C, share = (nfl + y.n_wg - 1) / y.n_wg;
+    float* t = zero_grid + (size_t)(uint32_t)offsets[level] * C;
+    const uint32_t lo = blockIdx.x * share, hi = min(nfl, lo + share);
+    for (uint32_t i = lo + tid; i < hi; i += HB_THREADS) t[i] = 0.f;
+  }
+  __syncthreads();
+
+  // ---- phase 1: runs of equal cells, rank of every run head's corners inside (workgroup, slice) ----
+  uint32_t rank2[HB_PTS][4];                 // two 13-bit ranks per word
+  uint32_t rid[HB_PTS];                      // run id inside the 16-lane row (>= 1), 255 = no contribution
+  uint32_t heads = 0;
+#pragma unroll
+  for (int p = 0; p < HB_PTS; ++p) {
+    const uint32_t b = (blockIdx.x * HB_PTS + p) * HB_THREADS + tid;
+    const HgCell c = hg_locate(inputs, lv, b < B ? b : B - 1);
+    const bool live = b < B && !c.oob;
+    const uint32_t k1 = live ? (c.gx | (c.gy << 16)) : 0xffffffffu, k2 = live ? c.gz : 0xffffffffu;
+    const uint32_t p1 = dpp_u32<DPP_ROW_SHR(1)>(k1), p2 = dpp_u32<DPP_ROW_SHR(1)>(k2);
+    const bool head = live && ((lane & 15) == 0 || p1 != k1 || p2 != k2);
+    const uint64_t hb = __ballot(head);
+    const uint32_t row = (uint32_t)(hb >> (lane & 48)) & 0xffffu;
+    rid[p] = live ? (uint32_t)__popc(row & ((2u << (lane & 15)) - 1u)) : 255u;
+    if (head) heads |= 1u << p;
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+      uint32_t r0 = 0, r1 = 0;
+      if (head) {
+        const uint32_t i0 = hg_index_lv(lv, c.gx + (k & 1), c.gy + ((k >> 1) & 1), c.gz + ((k >> 2) & 1));
+        const uint32_t i1 = hg_index_lv(lv, c.gx + ((k + 1) & 1), c.gy + (((k + 1) >> 1) & 1), c.gz + (((k + 1) >> 2) & 1));
+        r0 = (uint32_t)atomicAdd(&hist[i0 / epb], 1);
+        r1 = (uint32_t)atomicAdd(&hist[i1 / epb], 1);
+      }
+      rank2[p][k >> 1] = r0 | (r1 << 16);
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: exclusive scan of the slice counts -> run starts; the run table row of this workgroup ----
+  {
+    const int per = (ns + HB_THREADS - 1) / HB_THREADS;
+    const int lo = min(ns, tid * per), hi = min(ns, lo + per);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += hist[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < HB_THREADS; d <<= 1) {
+      const int a = (tid >= d) ? part[tid - d] : 0;
+      __syncthreads();
+      part[tid] += a;
+      __syncthreads();
+    }
+    int run = part[tid] - sum;
+    int* rt = ws + ((size_t)level * y.n_wg + blockIdx.x) * y.rt_stride;
+    for (int i = lo; i < hi; ++i) {
+      const int n = hist[i];
+      hist[i] = run;
+      rt[i] = run;
+      run += n;
+    }
+    if (tid == HB_THREADS - 1) rt[ns] = part[HB_THREADS - 1];
+    __syncthreads();
+  }
+
+  // ---- phase 3: the records ----
+  uint32_t* rec = (uint32_t*)((char*)ws + y.rec_off_bytes) +
+                  ((size_t)level * y.n_wg + blockIdx.x) * (8 * HB_PTS * HB_THREADS) * (1 + C);
+#pragma unroll
+  for (int p = 0; p < HB_PTS; ++p) {
+    const uint32_t b = (blockIdx.x * HB_PTS + p) * HB_THREADS + tid;
+    const uint32_t bc = b < B ? b : B - 1;
+    const HgCell c = hg_locate(inputs, lv, bc);
+    const bool live = rid[p] != 255u;
+    // lane i + d continues lane i's run?  (run ids of live lanes are >= 1, a read past the row's end gives 0)
+    const float m1 = (live && dpp_u32<DPP_ROW_SHL(1)>(rid[p]) == rid[p]) ? 1.f : 0.f;
+    const float m2 = (live && dpp_u32<DPP_ROW_SHL(2)>(rid[p]) == rid[p]) ? 1.f : 0.f;
+    const float m4 = (live && dpp_u32<DPP_ROW_SHL(4)>(rid[p]) == rid[p]) ? 1.f : 0.f;
+    const float m8 = (live && dpp_u32<DPP_ROW_SHL(8)>(rid[p]) == rid[p]) ? 1.f : 0.f;
+    const float wx[2] = {1.f - c.sx, c.sx}, wy[2] = {1.f - c.sy, c.sy}, wz[2] = {1.f - c.sz, c.sz};
+    float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+    if (MODE != 0) {
+      q0 = gg_inputs[(size_t)bc * 3 + 0] * c.dx * c.scale;
+      q1 = gg_inputs[(size_t)bc * 3 + 1] * c.dy * c.scale;
+      q2 = gg_inputs[(size_t)bc * 3 + 2] * c.dz * c.scale;
+    }
+    float g1[C], g2[C];
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) {
+      g1[ch] = live ? grad[((size_t)level * B + bc) * C + ch] : 0.f;
+      g2[ch] = (MODE == 2 && live) ? grad2[((size_t)level * B + bc) * C + ch] : 0.f;
+    }
+    const bool head = (heads >> p) & 1u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int bx = k & 1, by = (k >> 1) & 1, bz = (k >> 2) & 1;
+      const float wk = wx[bx] * wy[by] * wz[bz];
+      const float qk = (bx ? 1.f : -1.f) * wy[by] * wz[bz] * q0 + (by ? 1.f : -1.f) * wx[bx] * wz[bz] * q1 +
+                       (bz ? 1.f : -1.f) * wx[bx] * wy[by] * q2;
+      float v[C];
+#pragma unroll
+      for (int ch = 0; ch < C; ++ch) {
+        if (MODE == 0) v[ch] = wk * g1[ch];
+        else if (MODE == 1) v[ch] = qk * g1[ch];
+        else v[ch] = wk * g1[ch] + qk * g2[ch];
+      }
+      run_sum<C>(v, m1, m2, m4, m8);
+      if (head) {
+        const uint32_t idx = hg_index_lv(lv, c.gx + bx, c.gy + by, c.gz + bz);
+        const uint32_t pos = (uint32_t)hist[idx / epb] + ((rank2[p][k >> 1] >> ((k & 1) * 16)) & 0xffffu);
+        uint32_t* r = rec + (size_t)pos * (1 + C);
+        r[0] = idx % epb;
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) r[1 + ch] = __float_as_uint(v[ch]);
+      }
+    }
+  }
+}
+
+// entry e of the LDS accumulator += v[0..C): float adds as compare-and-swap loops, two channels per 64-bit swap
+template <int C>
+__device__ __forceinline__ void lds_add_entry(float* acc, const uint32_t e, const float (&v)[C]) {
+  if (C == 1) {
+    lds_add_cas(acc + e, v[0]);
+  } else {
+#pragma unroll
+    for (int h = 0; h < C / 2; ++h) {
+      unsigned long long* u = (unsigned long long*)(acc + (size_t)e * C + 2 * h);
+      unsigned long long old = *u;
+      while (true) {
+        const float a = __uint_as_float((uint32_t)old) + v[2 * h];
+        const float b = __uint_as_float((uint32_t)(old >> 32)) + v[2 * h + 1];
+        const unsigned long long want = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
+        const unsigned long long got = atomicCAS(u, old, want);
+        if (got == old) break;
+        old = got;
+      }
+    }
+  }
+}
+
+template <int C>
+__global__ void __launch_bounds__(HB_THREADS)
+hb2_accumulate_k(const int* __restrict__ ws, const Hb2Layout y, const int* __restrict__ offsets, const uint32_t L,
+                 float* __restrict__ grad_grid, const int overwrite) {
+  __shared__ __attribute__((aligned(16))) float acc[HB_SLICE_FLOATS];      // [entry][C]
+  __shared__ int pre[HB2_TILE + 1], st[HB2_TILE];
+  constexpr uint32_t epb = HB_SLICE_FLOATS / C;
+  // work item -> (level, slice, group of place workgroups): a function of the level sizes alone
+  int w = blockIdx.x;
+  uint32_t level = 0, hsize = 0;
+  int ns = 0, G = 0;
+  for (; level < L; ++level) {
+    hsize = (uint32_t)(offsets[level + 1] - offsets[level]);
+    ns = (int)((hsize + epb - 1) / epb);
+    G = min(ns, y.n_wg);
+    const int items = (G > 0) ? ns * ((y.n_wg + G - 1) / G) : 0;
+    if (w < items) break;
+    w -= items;
+  }
+  if (level >= L) return;
+  const int slice = w % ns, wg0 = (w / ns) * G, wg1 = min(y.n_wg, wg0 + G);
+  const bool shared_slice = G < y.n_wg;
+  const int tid = threadIdx.x;
+  for (uint32_t i = tid; i < HB_SLICE_FLOATS / 4; i += HB_THREADS) ((v4f*)acc)[i] = (v4f){0.f, 0.f, 0.f, 0.f};
+  const uint32_t* rec_all = (const uint32_t*)((const char*)ws + y.rec_off_bytes);
+  constexpr size_t REGION = (size_t)(8 * HB_PTS * HB_THREADS) * (1 + C);        // dwords per place workgroup
+  for (int t0 = wg0; t0 < wg1; t0 += HB2_TILE) {
+    // this pass's runs: start and length per place workgroup, inclusive scan of the lengths
+    const int wg = t0 + tid;
+    int s0 = 0, n = 0;
+    if (tid < HB2_TILE && wg < wg1) {
+      const int* r = ws + ((size_t)level * y.n_wg + wg) * y.rt_stride + slice;
+      s0 = r[0];
+      n = r[1] - s0;
+    }
+    __syncthreads();                       // previous pass done with pre / st (and the zero fill, first pass)
+    st[tid] = s0;
+    pre[tid + 1] = n;
+    if (tid == 0) pre[0] = 0;
+    __syncthreads();
+    for (int d = 1; d < HB2_TILE; d <<= 1) {
+      const int a = (tid >= d) ? pre[tid + 1 - d] : 0;
+      __syncthreads();
+      pre[tid + 1] += a;
+      __syncthreads();
+    }
+    const int total = pre[HB2_TILE];
+    constexpr int U = 4;
+    for (int i0 = tid; i0 < total; i0 += U * HB_THREADS) {
+      uint32_t e[U];
+      float v[U][C];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = min(i0 + u * HB_THREADS, total - 1);       // every load issued (index clamped), adds guarded below
+        int j = 0;                                                // largest j with pre[j] <= i
+#pragma unroll
+        for (int step = HB2_TILE / 2; step > 0; step >>= 1)
+          if (pre[j + step] <= i) j += step;
+        const uint32_t* r = rec_all + ((size_t)level * y.n_wg + t0 + j) * REGION + (size_t)(st[j] + i - pre[j]) * (1 + C);
+        e[u] = r[0];
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) v[u][ch] = __uint_as_float(r[1 + ch]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (i0 + u * HB_THREADS < total) lds_add_entry<C>(acc, e[u], v[u]);
+    }
+  }
+  __syncthreads();
+  const uint32_t e0 = (uint32_t)slice * epb;
+  const uint32_t nf = min(epb, hsize - e0) * C;
+  float* table = grad_grid + ((size_t)(uint32_t)offsets[level] + e0) * C;
+  if (!shared_slice) {
+    // this workgroup owns the slice: plain read-modify-write, one entry (C floats) per lane and step.  Level offsets
+    // are arbitrary entry counts (12,167 ...), so a table row is aligned to one entry, not to 16 bytes.
+    typedef float vcf __attribute__((ext_vector_type(C)));
+    vcf* tc = (vcf*)table;
+    const vcf* ac = (const vcf*)acc;
+    const uint32_t ne = nf / C;
+    if (overwrite) {                       // the table gradient is an output, not an accumulator: nothing to read
+      for (uint32_t i = tid; i < ne; i += HB_THREADS) tc[i] = ac[i];
+    } else {
+      constexpr int UF = 8;
+      for (uint32_t i0 = tid; i0 < ne; i0 += UF * HB_THREADS) {
+        vcf t[UF];
+#pragma unroll
+        for (int u = 0; u < UF; ++u) t[u] = tc[min(i0 + u * HB_THREADS, ne - 1)];
+#pragma unroll
+        for (int u = 0; u < UF; ++u) {
+          const uint32_t i = i0 + u * HB_THREADS;
+          if (i < ne) tc[i] = t[u] + ac[i];
+        }
+      }
+    }
+  } else {
+    for (uint32_t i = tid; i < nf; i += HB_THREADS) {
+      const float v = acc[i];
+      if (v != 0.f) unsafeAtomicAdd(table + i, v);  // neighbouring lanes, neighbouring floats: the fast atomic shape
+    }
+  }
+}
+
+// MSDF_HASH_SCATTER=1 keeps the first form (count / scan / place / accumulate) for comparison runs
+static bool hb_force_first_form() {
+  static const int v = [] { const char* e = getenv("MSDF_HASH_SCATTER"); return (e && e[0] == '1') ? 1 : 0; }();
+  return v != 0;
+}
+
 template <int C, int MODE>
 static int hb_run(const float* grad, const float* grad2, const float* inputs, const int* offsets,
                   const float* gg_inputs, float* grad_grid, const uint32_t B, const uint32_t L, const float S,
                   const uint32_t H, const uint64_t n_entries, void* workspace, const size_t workspace_bytes,
-                  hipStream_t st) {
+                  hipStream_t st, const bool overwrite = false) {
+  if (n_entries * C >= (1ull << 31) || (uint64_t)B * L * 8 >= (1ull << 31)) return MSDF_ERR_UNSUPPORTED;
+  int* ws = (int*)workspace;
+  const Hb2Layout y2 = hb2_layout(B, C, L, n_entries);
+  if (y2.ns_bound <= HB2_NS_MAX && !hb_force_first_form()) {
+    if (workspace == nullptr || workspace_bytes < y2.total_bytes || ((uintptr_t)workspace & 15)) return MSDF_ERR_ARG;
+    const size_t lds = (size_t)(y2.ns_bound + 1 + HB_THREADS) * sizeof(int);
+    hb2_place_k<C, MODE><<<dim3((unsigned)y2.n_wg, L), HB_THREADS, lds, st>>>(grad, grad2, inputs, offsets, gg_inputs, ws,
+                                                                             y2, B, S, H, overwrite ? grad_grid : nullptr);
+    hb2_accumulate_k<C><<<(unsigned)y2.work_max, HB_THREADS, 0, st>>>(ws, y2, offsets, L, grad_grid, overwrite ? 1 : 0);
+    return MSDF_OK;
+  }
+  if (overwrite && hipMemsetAsync(grad_grid, 0, (size_t)n_entries * C * sizeof(float), st) != hipSuccess) return MSDF_ERR_LAUNCH;
   const HbLayout y = hb_layout(B, C, L, n_entries);
   if (workspace == nullptr || workspace_bytes < y.total_bytes || ((uintptr_t)workspace & 15)) return MSDF_ERR_ARG;
-  if (n_entries * C >= (1ull << 31)) return MSDF_ERR_UNSUPPORTED;
-  int* ws = (int*)workspace;
   const dim3 grid_pl((B + HB_PTS * HB_THREADS - 1) / (HB_PTS * HB_THREADS), L);
   hb_setup_k<<<1, HB_THREADS, 0, st>>>(ws, y, offsets, L, C);
   hb_count_k<C><<<grid_pl, HB_THREADS, 0, st>>>(inputs, offsets, ws, y, B, S, H);
@@ -742,7 +1111,8 @@ extern "C" int msdf_hash_encode_backward(const float* grad, const float* inputs,
 }
 
 extern "C" int64_t msdf_hash_scatter_workspace_bytes(uint32_t B, uint32_t C, uint32_t L, uint64_t n_entries) {
-  return (int64_t)hb_layout(B, C, L, n_entries).total_bytes;
+  const size_t a = hb_layout(B, C, L, n_entries).total_bytes, b = hb2_layout(B, C, L, n_entries).total_bytes;
+  return (int64_t)(a > b ? a : b);
 }
 
 extern "C" int msdf_hash_encode_backward_ws(const float* grad, const float* inputs, const float* embeddings,
@@ -808,6 +1178,28 @@ extern "C" int msdf_hash_encode_backward_fused(const float* grad_first, const fl
   HG_DISPATCH_C(C, {
     const int rc = hb_run<CC, 2>(grad_first, grad_second, inputs, offsets, grad_grad_inputs, grad_embeddings, B, L, S,
                                  H, n_entries, workspace, workspace_bytes, st);
+    if (rc != MSDF_OK) return rc;
+  });
+  return msdf_check_launch();
+}
+
+// the same with "=" instead of "+=": grad_embeddings need not be initialised (no 48.8 MB fill before the call, no
+// read of the table inside it)
+extern "C" int msdf_hash_encode_backward_fused_out(const float* grad_first, const float* grad_second,
+                                                   const float* inputs, const int* offsets, float* grad_embeddings,
+                                                   uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                                   const float* grad_grad_inputs, uint64_t n_entries, void* workspace,
+                                                   uint64_t workspace_bytes, void* stream) {
+  if (D != 3 || C == 1) return MSDF_ERR_UNSUPPORTED;
+  if (grad_embeddings == nullptr || grad_first == nullptr || grad_second == nullptr || grad_grad_inputs == nullptr)
+    return MSDF_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0)
+    return hipMemsetAsync(grad_embeddings, 0, (size_t)n_entries * C * sizeof(float), st) == hipSuccess ? MSDF_OK
+                                                                                                      : MSDF_ERR_LAUNCH;
+  HG_DISPATCH_C(C, {
+    const int rc = hb_run<CC, 2>(grad_first, grad_second, inputs, offsets, grad_grad_inputs, grad_embeddings, B, L, S,
+                                 H, n_entries, workspace, workspace_bytes, st, true);
     if (rc != MSDF_OK) return rc;
   });
   return msdf_check_launch();

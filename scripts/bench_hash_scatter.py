@@ -59,7 +59,10 @@ def main():
                                           C, L, Sc, H, P(gg), n, P(ws), nbytes, st),
     }
     res = {'points': B, 'workspace_MB': nbytes / 1e6, 'pts': os.environ.get('PTS', 'rays')}
+    only = os.environ.get('ONLY')
     for name, fn in calls.items():
+        if only and name not in only.split(','):
+            continue
         for _ in range(3):
             fn()
         torch.cuda.synchronize()

@@ -20,8 +20,8 @@ def golden_dir():
 
 
 # Measured errors of the GPU parity tests: every comparison calls errlog(test, case, key, err, tol); the table is
-# written to gpurun_out/parity_errors.json at the end of the session (scripts/parity_table.py turns it into
-# profiles/rNN_parity_errors.md -- the tolerances in the tests are ratcheted against it).
+# written to gpurun_out/parity_errors.json at the end of the session (scripts/parity_table.py check turns it into
+# profiles/rNN_parity_errors.md and verifies it against the frozen table tests/golden/tolerances.json).
 _ERRLOG = []
 
 

@@ -216,6 +216,67 @@ def test_fullsize_binned_scatter_equals_atomic_scatter():
     assert torch.equal(b1 != 0, a1 != 0)
 
 
+def test_fullsize_scatter_of_ray_ordered_samples_and_output_form():
+    """The place kernel of the binned scatter sums consecutive points that sit in one cell before it writes a record
+    (runs inside 16-lane rows).  Ray-ordered samples 2e-4 apart give runs of every length on every level, some points
+    outside [0, 1] (no contribution) break them; against the one-atomic-per-corner kernels.  And the "=" form
+    (msdf_hash_encode_backward_fused_out) into an uninitialised buffer equals the "+=" form into zeros."""
+    from monosdf_amd import _lib
+    from monosdf_amd.hashencoder.hashgrid import HashEncoder
+    enc = HashEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19,
+                      desired_resolution=2048).cuda()
+    n_rays, per = 400, 98
+    B, L, C = n_rays * per + 37, 16, 2
+    g = torch.Generator(device='cuda').manual_seed(9)
+    o = torch.rand(n_rays, 1, 3, device='cuda', generator=g) * 0.8 + 0.1
+    d = torch.nn.functional.normalize(torch.randn(n_rays, 1, 3, device='cuda', generator=g), dim=-1)
+    # step sizes from 2e-5 (runs of 64+ at the coarse levels) to 5e-3 per ray
+    step = (2e-5 * (250.0 ** torch.rand(n_rays, 1, 1, device='cuda', generator=g)))
+    t = torch.arange(per, device='cuda').view(1, per, 1) * step
+    x = (o + t * d).reshape(-1, 3)
+    x = torch.cat([x, torch.rand(37, 3, device='cuda', generator=g)])
+    x[5::97] = 1.5                                  # out of range: contributes nothing, breaks a run
+    x[1000:1100] = x[1000]                          # 100 identical points across rows and waves
+    x = x.contiguous()
+    grad = torch.randn(L, B, C, device='cuda', generator=g)
+    grad2 = torch.randn(L, B, C, device='cuda', generator=g)
+    gg = torch.randn(B, 3, device='cuda', generator=g)
+    emb, offs = enc.embeddings.detach(), enc.offsets
+    n = emb.shape[0]
+    S, H = enc.log2_scale, int(enc.base_resolution)
+    st = _lib.stream_ptr()
+    dy = torch.empty(B, L * 3 * C, device='cuda')
+    out = torch.empty(L, B, C, device='cuda')
+    _lib.call('msdf_hash_encode_forward', _lib.ptr(x), _lib.ptr(emb), _lib.ptr(offs), _lib.ptr(out), B, 3, C, L, S, H, 1,
+              _lib.ptr(dy), st)
+    a1, a2 = torch.zeros_like(emb), torch.zeros_like(emb)
+    gi, ggrad = torch.zeros_like(x), torch.zeros(L, B, C, device='cuda')
+    _lib.call('msdf_hash_encode_backward', _lib.ptr(grad), _lib.ptr(x), _lib.ptr(emb), _lib.ptr(offs), _lib.ptr(a1),
+              B, 3, C, L, S, H, 0, _lib.ptr(dy), _lib.ptr(gi), st)
+    _lib.call('msdf_hash_encode_second_backward', _lib.ptr(grad2), _lib.ptr(x), _lib.ptr(emb), _lib.ptr(offs), B, 3, C, L,
+              S, H, 1, _lib.ptr(dy), _lib.ptr(gg), _lib.ptr(ggrad), _lib.ptr(a2), st)
+    nbytes = _lib.load().msdf_hash_scatter_workspace_bytes(B, C, L, n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+    b1, bf = torch.zeros_like(emb), torch.zeros_like(emb)
+    bo = torch.full_like(emb, float('nan'))
+    _lib.call('msdf_hash_encode_backward_ws', _lib.ptr(grad), _lib.ptr(x), _lib.ptr(emb), _lib.ptr(offs), _lib.ptr(b1),
+              B, 3, C, L, S, H, 0, _lib.ptr(dy), None, n, _lib.ptr(ws), nbytes, st)
+    _lib.call('msdf_hash_encode_backward_fused', _lib.ptr(grad), _lib.ptr(grad2), _lib.ptr(x), _lib.ptr(offs), _lib.ptr(bf),
+              B, 3, C, L, S, H, _lib.ptr(gg), n, _lib.ptr(ws), nbytes, st)
+    _lib.call('msdf_hash_encode_backward_fused_out', _lib.ptr(grad), _lib.ptr(grad2), _lib.ptr(x), _lib.ptr(offs),
+              _lib.ptr(bo), B, 3, C, L, S, H, _lib.ptr(gg), n, _lib.ptr(ws), nbytes, st)
+    rel = lambda a, b: ((a - b).abs().max() / b.abs().max()).item()
+    assert rel(b1, a1) < 1e-4, rel(b1, a1)
+    assert rel(bf, a1 + a2) < 1e-4, rel(bf, a1 + a2)
+    assert torch.equal(b1 != 0, a1 != 0)
+    assert torch.isfinite(bo).all()
+    assert rel(bo, a1 + a2) < 1e-4, rel(bo, a1 + a2)
+    # per level, so that a fine level's error cannot hide under a coarse level's magnitude
+    for l in range(L):
+        lo, hi = int(offs[l]), int(offs[l + 1])
+        assert rel(bo[lo:hi], (a1 + a2)[lo:hi]) < 2e-4, (l, rel(bo[lo:hi], (a1 + a2)[lo:hi]))
+
+
 def _record(name, payload):
     """Times of the full-size runs go to gpurun_out/r02_fullsize.json (copied to profiles/ by hand)."""
     import json

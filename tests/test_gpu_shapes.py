@@ -6,7 +6,7 @@ same code of the oracle with other sizes."""
 import pytest
 import torch
 
-from helpers import TOL, rel_err
+from helpers import TOL, check, rel_err
 from oracle import config, synth
 
 pytestmark = pytest.mark.gpu
@@ -27,7 +27,7 @@ def _build(width, depth, precision):
 
 
 @pytest.mark.parametrize('width,depth', SHAPES)
-def test_sdf_network_forward_gradient_and_double_backward(width, depth):
+def test_sdf_network_forward_gradient_and_double_backward(width, depth, errlog):
     from oracle import monosdf_oracle as mo
     conf, state, m = _build(width, depth, 'fp32')
     m.train()
@@ -47,12 +47,11 @@ def test_sdf_network_forward_gradient_and_double_backward(width, depth):
     loss.backward()
     params = dict(m.named_parameters())
     for n, go in zip(names, g_o):
-        # second-order sums with cancellation: the bar of the golden geometries' double-backward test
-        assert rel_err(params[n].grad, go) < 2 * TOL, (n, rel_err(params[n].grad, go))
+        check(errlog, 'shapes_double_backward', '%dx%d' % (depth, width), n, rel_err(params[n].grad, go))
 
 
 @pytest.mark.parametrize('width,depth', [(48, 5), (100, 3), (176, 5)])
-def test_training_forward_and_gradients(width, depth):
+def test_training_forward_and_gradients(width, depth, errlog):
     """The whole pass (sampler, both networks, compositor, eikonal block) and the gradients of the probe loss."""
     from oracle import monosdf_oracle as mo
     conf, state, m = _build(width, depth, 'fp32')
@@ -65,8 +64,9 @@ def test_training_forward_and_gradients(width, depth):
     ref = mo.render(st, conf, rays, idx, True, True, noise)
     m._noise = {k: v.cuda() for k, v in noise.items()}
     out = m({k: v.cuda() for k, v in rays.items()}, idx.cuda(), if_pixel_input=True)
+    case = '%dx%d' % (depth, width)
     for k in ('rgb_values', 'depth_values', 'normal_map', 'weights', 'sdf', 'grad_theta'):
-        assert rel_err(out[k], ref[k]) < 5 * TOL, (k, rel_err(out[k], ref[k]))      # 1-round sampler cases: 1e-4-ish
+        check(errlog, 'shapes_training', case, k, rel_err(out[k], ref[k]))
     loss_o = mo.probe_loss(ref)
     names = [k for k, v in st.items() if v.requires_grad]
     g_o = dict(zip(names, torch.autograd.grad(loss_o, [st[k] for k in names], allow_unused=True)))
@@ -74,7 +74,7 @@ def test_training_forward_and_gradients(width, depth):
     for k, p in m.named_parameters():
         if g_o.get(k) is None:
             continue
-        assert rel_err(p.grad, g_o[k]) < 5 * TOL, (k, rel_err(p.grad, g_o[k]))
+        check(errlog, 'shapes_training', case, k, rel_err(p.grad, g_o[k]))
 
 
 def test_too_wide_network_is_refused():
@@ -114,31 +114,58 @@ VARIANTS = {
 }
 
 
+def _relu_units_near_zero(fn, thresh=1e-6):
+    """Runs fn() with torch.relu wrapped; returns (result, per relu call the boolean mask of the units whose input comes
+    within `thresh` of zero for some sample).  Such a unit's ReLU switch can differ between two fp32 summation orders of
+    the same dot product, and with it that sample's whole contribution to the unit's row of the weight gradient."""
+    masks = []
+    real = torch.relu
+
+    def spy(h):
+        masks.append((h.detach().abs().reshape(-1, h.shape[-1]).min(0)[0] < thresh))
+        return real(h)
+    torch.relu = spy
+    try:
+        res = fn()
+    finally:
+        torch.relu = real
+    return res, masks
+
+
 @pytest.mark.parametrize('name', sorted(VARIANTS))
-def test_config_options_against_oracle(name):
+def test_config_options_against_oracle(name, errlog):
     """Options of the reference's conf files the goldens leave at their usual values: one training pass (forward
-    outputs and the gradients of the probe loss) against the oracle."""
+    outputs and the gradients of the probe loss) against the oracle.  Bars: 1e-4 unless tests/golden/tolerances.json
+    lists the comparison (`options|<variant>|<tensor>`)."""
     from oracle import monosdf_oracle as mo
-    # weight seed 21 puts one ReLU input of the colour network's first layer at 9.9e-8 in the 'no_skip' network: its
-    # sign differs between two fp32 summation orders and with it a whole row of that layer's gradient (5e-4)
-    conf, state, m = _variant(VARIANTS[name], seed=23 if name == 'no_skip' else 21)
+    conf, state, m = _variant(VARIANTS[name], seed=21)
     m.train()
     n = 16
     rays = synth.make_rays(n, seed=6, random_pose=True)
     noise = synth.make_noise(conf, n, 128, seed=8)
     idx = torch.arange(n) % 5
     st = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in state.items()}
-    ref = mo.render(st, conf, rays, idx, True, True, noise)
+    # weight seed 21 puts one ReLU input of the colour network's first layer at 9.9e-8 in the 'no_skip' network: the rows
+    # of such units are left out of that layer's gradient comparison (the unit is found in the ORACLE's pre-activations)
+    ref, near_zero = _relu_units_near_zero(lambda: mo.render(st, conf, rays, idx, True, True, noise))
     m._noise = {k: v.cuda() for k, v in noise.items()}
     out = m({k: v.cuda() for k, v in rays.items()}, idx.cuda(), if_pixel_input=True)
     for k in ('rgb_values', 'depth_values', 'normal_map', 'weights', 'sdf', 'grad_theta'):
-        assert rel_err(out[k], ref[k]) < 5 * TOL, (k, rel_err(out[k], ref[k]))
+        check(errlog, 'options', name, k, rel_err(out[k], ref[k]))
     names = [k for k, v in st.items() if v.requires_grad]
     g_o = dict(zip(names, torch.autograd.grad(mo.probe_loss(ref), [st[k] for k in names], allow_unused=True)))
     mo.probe_loss(out).backward()
     for k, p in m.named_parameters():
-        if g_o.get(k) is not None:
-            assert rel_err(p.grad, g_o[k]) < 5 * TOL, (k, rel_err(p.grad, g_o[k]))
+        if g_o.get(k) is None:
+            continue
+        g, gr = p.grad.detach().cpu(), g_o[k]
+        if k.startswith('rendering_network.lin'):
+            layer = int(k.split('.')[1][3:])
+            if layer < len(near_zero) and bool(near_zero[layer].any()):
+                keep = ~near_zero[layer]
+                assert int(keep.sum()) >= keep.numel() - 4, 'more than four units at a ReLU switch: pick another seed'
+                g, gr = g[keep], gr[keep]
+        check(errlog, 'options', name, k, rel_err(g, gr))
 
 
 def test_wide_positional_encoding_is_refused():
@@ -157,7 +184,7 @@ SAMPLER_VARIANTS = {
 
 
 @pytest.mark.parametrize('name', sorted(SAMPLER_VARIANTS))
-def test_sampler_options_against_oracle(name):
+def test_sampler_options_against_oracle(name, errlog):
     """Sampler settings other than the ones every conf of the reference uses (64 / 128 / 32 samples, eps 0.1, 10
     bisection steps, 5 rounds): a sharp state (beta 0.01, 2+ rounds) in eval mode -- z_vals and the rendered values
     against the oracle -- or a clear refusal."""
@@ -183,9 +210,9 @@ def test_sampler_options_against_oracle(name):
     ref = {k: v.detach() for k, v in ref.items()}
     assert out['z_vals'].shape == ref['z_vals'].shape
     far = mo.sampler_far(conf)
-    assert (out['z_vals'].cpu() - ref['z_vals']).abs().max().item() / far < 2e-3      # inverse-CDF conditioning, DESIGN 2
+    check(errlog, 'sampler_options', name, 'z_vals', (out['z_vals'].cpu() - ref['z_vals']).abs().max().item() / far)
     for k in ('rgb_values', 'depth_values'):
-        assert rel_err(out[k], ref[k]) < 2e-3, (k, rel_err(out[k], ref[k]))
+        check(errlog, 'sampler_options', name, k, rel_err(out[k], ref[k]))
 
 
 GRID_VARIANTS = {
@@ -196,7 +223,7 @@ GRID_VARIANTS = {
 
 
 @pytest.mark.parametrize('name', sorted(GRID_VARIANTS))
-def test_hash_grid_model_variants_against_oracle(name):
+def test_hash_grid_model_variants_against_oracle(name, errlog):
     """Hash-grid models with other level counts / features per level than the reference's 16 x 2 (through the fused
     encoding + MLP node, embedding gradients included) against the oracle.  Hash arithmetic: parity unpinned by
     reference outputs (README) -- this pins the wiring for other table geometries."""
@@ -218,16 +245,13 @@ def test_hash_grid_model_variants_against_oracle(name):
     m._noise = {k: v.cuda() for k, v in noise.items()}
     out = m({k: v.cuda() for k, v in rays.items()}, idx.cuda(), if_pixel_input=True)
     for k in ('rgb_values', 'depth_values', 'normal_map', 'weights', 'sdf', 'grad_theta'):
-        assert rel_err(out[k], ref[k]) < 5 * TOL, (k, rel_err(out[k], ref[k]))
+        check(errlog, 'grid_variants', name, k, rel_err(out[k], ref[k]))
     names = [k for k, v in st.items() if v.requires_grad]
     g_o = dict(zip(names, torch.autograd.grad(mo.probe_loss(ref), [st[k] for k in names], allow_unused=True)))
     mo.probe_loss(out).backward()
     for k, p in m.named_parameters():
         if g_o.get(k) is not None:
-            # embedding gradients: first- and second-order terms of opposite sign summed per entry -- the oracle's own
-            # fp32 result is 2e-4 from its fp64 result on this tensor (8 levels x 4 features case)
-            bar = 2e-3 if k.endswith('encoding.embeddings') else 5 * TOL
-            assert rel_err(p.grad, g_o[k]) < bar, (k, rel_err(p.grad, g_o[k]))
+            check(errlog, 'grid_variants', name, k, rel_err(p.grad, g_o[k]))
 
 
 @pytest.mark.parametrize('P', [0, 1, 15, 16, 17, 63, 65])
@@ -264,7 +288,7 @@ MODE_VARIANTS = {
 
 
 @pytest.mark.parametrize('name', sorted(MODE_VARIANTS))
-def test_input_and_output_modes_against_oracle(name):
+def test_input_and_output_modes_against_oracle(name, errlog):
     """Combinations of uv / pixel input, train / eval, white background, per-image code and HDR output that no single
     golden holds together."""
     import numpy as np
@@ -301,11 +325,11 @@ def test_input_and_output_modes_against_oracle(name):
     assert set(out) == set(ref)
     for k in ref:
         assert out[k].shape == ref[k].shape, k
-        assert rel_err(out[k], ref[k]) < 5 * TOL, (k, rel_err(out[k], ref[k]))
+        check(errlog, 'modes', name, k, rel_err(out[k], ref[k]))
     if training:
         names = [k for k, v in st.items() if v.requires_grad]
         g_o = dict(zip(names, torch.autograd.grad(mo.probe_loss(ref), [st[k] for k in names], allow_unused=True)))
         mo.probe_loss(out).backward()
         for k, p in m.named_parameters():
             if g_o.get(k) is not None and p.grad is not None:
-                assert rel_err(p.grad, g_o[k]) < 5 * TOL, (k, rel_err(p.grad, g_o[k]))
+                check(errlog, 'modes', name, k, rel_err(p.grad, g_o[k]))

@@ -179,3 +179,35 @@ def test_cpu_tensors_fail_loudly():
     m = MonoSDFNetwork(ConfigTree.from_dict(config.mlp_config(64)))
     with pytest.raises(RuntimeError):
         m.implicit_network.get_outputs(torch.zeros(4, 3))
+
+
+def test_tolerance_table_is_frozen_and_bounded(capsys):
+    """tests/golden/tolerances.json is reviewed data (scripts/parity_table.py never widens it): every entry stays within
+    max(1e-4, 2 x the reference's own deviation on that tensor) -- the independent yardsticks of
+    profiles/r03_reference_sensitivity.json -- or carries a hand-written cause.  Prints the counts the review asks for."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'scripts'))
+    import parity_table as pt
+    doc = json.load(open(pt.TABLE))
+    yard = json.load(open(pt.YARD))['cases']
+    table = doc['tolerances']
+    assert 'frozen' in doc
+    assert pt.violations(table, yard) == []
+    generic = {pt.auto_cause(t, y, k) for t in ('forward_golden.fp32', 'forward_golden.bf16x3') for y in (None,) for k in (None,)}
+    n_f32 = n_hand = 0
+    for key, ent in table.items():
+        test, case, tensor = key.split('|')
+        assert ent['tol'] > pt.BAR, key                       # an entry at or under the bar is no entry
+        assert ent['tol'] <= 3.0 * ent['measured'], key      # no slack beyond the measured error's own scale
+        if ent.get('hand'):
+            n_hand += 1
+            assert len(ent['cause']) > 80 and ent['cause'] not in generic, key
+        if 'bf16x3' not in test:
+            n_f32 += 1
+            y, _ = pt.yardstick(yard, test, case, tensor)
+            assert ent.get('hand') or ent['tol'] <= 2.2 * max(y or 0.0, pt.BAR / 2), key
+    with capsys.disabled():
+        print('\ntolerance table: %d entries; fp32 core above 1e-4: %d (all within 2 x the reference yardstick or with a '
+              'hand-written cause: %d hand-written in the whole table)' % (len(table), n_f32, n_hand))
