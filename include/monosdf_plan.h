@@ -41,12 +41,14 @@ typedef struct {
   int32_t hsum;         /* total hidden slots  = sum 16*ot over hidden layers */
   int32_t qsum;         /* total q-bar slots   = sum 16*kt over hidden layers */
   int32_t absum;        /* total a-bar slots   = sum 16*ot over all layers */
-  int32_t wsdf_off;     /* float offset (packed bias buffer) of the sdf row of the last layer, per input slot;
-                           < 0: this plan has no sdf row (colour network) */
+  int32_t wsdf_off;     /* float offset (packed bias buffer) of `out_rows` rows of the LAST layer's weight, each as
+                           16 * kt floats in input-slot order: the sdf row (SDF network) / the three colour rows
+                           (colour network) -- outputs the kernels form as dot products instead of a matrix product */
   int32_t mode;         /* colour network: 1 = idr input [x, PE(v), n, feat], 0 = nerf [PE(v), feat]; sdf: unused */
   int32_t out_act;      /* colour network: 0 sigmoid, 1 relu (if_hdr) */
   int32_t precision;    /* MSDF_PRECISION_*: which matrix core the kernels run this plan on.  BF16X3 plans count
                            K in blocks of 32 slots (ktp / otp) and their wf_off / wb_off address bf16 hi/lo packs */
+  int32_t out_rows;     /* rows packed at wsdf_off: slots sdf_slot .. sdf_slot + out_rows - 1 of the last layer */
   msdf_layer_t layer[MSDF_MAX_LAYERS];
 } msdf_plan_t;
 

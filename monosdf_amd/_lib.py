@@ -23,7 +23,7 @@ class Layer(C.Structure):
 class Plan(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ('n_layers', 'e_tiles', 'aux_tiles', 'n_freqs', 'sdf_slot', 'feat_tiles', 'hsum',
-                 'qsum', 'absum', 'wsdf_off', 'mode', 'out_act', 'precision')] + [('layer', Layer * MAX_LAYERS)]
+                 'qsum', 'absum', 'wsdf_off', 'mode', 'out_act', 'precision', 'out_rows')] + [('layer', Layer * MAX_LAYERS)]
 
 
 class PackRule(C.Structure):

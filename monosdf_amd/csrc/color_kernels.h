@@ -164,20 +164,44 @@ __device__ __forceinline__ void color_forward_body(const msdf_plan_t& plan, cons
   const msdf_layer_t U1 = plan.layer[1];
   Core::gemm(U1.ktp, acc, in, U1.ot, (const wvec*)a.wpack + U1.wf_off, lds, next_hooks(2));
   // ---- hidden layers
-  for (int u = 2; u < nu; ++u) {
+#ifndef MSDF_DOT_FWD
+#define MSDF_DOT_FWD 1
+#endif
+  const bool dot_out = MSDF_DOT_FWD && nu >= 3;             // the output layer behind a hidden one: three dot products, not a product
+  for (int u = 2; u < (dot_out ? nu - 1 : nu); ++u) {
     const msdf_layer_t L = plan.layer[u];
 #pragma unroll
     for (int t = 0; t < MT; ++t) in[t] = (t < L.kt) ? acc[t] : V4ZERO;
     load_bias_c(acc, a.bpack + L.bias_off, L.ot, q);
     Core::gemm(L.ktp, acc, in, L.ot, (const wvec*)a.wpack + L.wf_off, lds, next_hooks(u + 1));
   }
-  // ---- output activation: slots 0..2 sit in tile 0, quarter 0
-  if (valid && q == 0) {
+  // ---- output layer: rgb_c = w_c . relu(h) + b_c over the register-resident activation (a 16-row matrix tile
+  // with 13 rows of zeros would be one dependent chain of 64 matrix instructions behind a weight chunk of its own)
+  float o0 = acc[0][0], o1 = acc[0][1], o2 = acc[0][2];
+  if (dot_out) {
+    const msdf_layer_t LO = plan.layer[nu - 1];
+    const float* w = a.bpack + plan.wsdf_off + 4 * q;
+    const int ld = 16 * LO.kt;
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const float v = acc[0][r];
-      a.rgb[(size_t)pt * 3 + r] = (plan.out_act == 1) ? fmaxf(v, 0.f) : 1.0f / (1.0f + fast_exp(-v));
+    for (int t = 0; t < MT; ++t) {
+      if (t < LO.kt) {
+        const v4f w0 = *(const v4f*)(w + 16 * t), w1 = *(const v4f*)(w + ld + 16 * t), w2 = *(const v4f*)(w + 2 * ld + 16 * t);
+        const v4f h = acc[t];
+        p0 += w0.x * h.x + w0.y * h.y + w0.z * h.z + w0.w * h.w;
+        p1 += w1.x * h.x + w1.y * h.y + w1.z * h.z + w1.w * h.w;
+        p2 += w2.x * h.x + w2.y * h.y + w2.z * h.z + w2.w * h.w;
+      }
     }
+    o0 = sum_over_quarters(p0) + a.bpack[LO.bias_off + 0];
+    o1 = sum_over_quarters(p1) + a.bpack[LO.bias_off + 1];
+    o2 = sum_over_quarters(p2) + a.bpack[LO.bias_off + 2];
+  }
+  if (valid && q == 0) {
+    const float o[3] = {o0, o1, o2};
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      a.rgb[(size_t)pt * 3 + r] = (plan.out_act == 1) ? fmaxf(o[r], 0.f) : 1.0f / (1.0f + fast_exp(-o[r]));
   }
 }
 
@@ -195,9 +219,10 @@ __device__ __forceinline__ void color_backward_body(const msdf_plan_t& plan, con
   v4f in[MT], acc[MT];
   zero_tiles(in);
   // ---- a-bar of the output layer
+  float ab0 = 0.f, ab1 = 0.f, ab2 = 0.f;     // a-bar of the three colour rows, in every quarter lane of the point
   {
     v4f ab = V4ZERO;
-    if (valid && q == 0) {
+    if (valid) {
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         const float y = a.rgb[(size_t)pt * 3 + r];
@@ -205,13 +230,50 @@ __device__ __forceinline__ void color_backward_body(const msdf_plan_t& plan, con
         ab[r] = (plan.out_act == 1) ? ((y > 0.f) ? g : 0.f) : g * y * (1.0f - y);
       }
     }
+    ab0 = ab[0]; ab1 = ab[1]; ab2 = ab[2];
+    if (q != 0) ab = V4ZERO;                  // slots 0..2 sit in tile 0, quarter 0
     in[0] = ab;
     const msdf_layer_t LL = plan.layer[nu - 1];
     float* ABl = a.AB + (size_t)LL.abpre * Pp + (size_t)pt * (16 * LL.ot) + 4 * q;
     *(v4f*)ABl = ab;
   }
+  // ---- output layer behind a hidden one: h-bar = sum_c a-bar_c w_c as an outer product over the activation's slots
+  // (the 3-row matrix product was 8 weight chunks of 8 matrix instructions each), masked and stored like a hook does
+#ifndef MSDF_DOT_BWD
+#define MSDF_DOT_BWD 1
+#endif
+  const bool dot_out = MSDF_DOT_BWD && nu >= 3;
+  if (dot_out) {
+    const msdf_layer_t L = plan.layer[nu - 1];
+    const float a0 = ab0, a1 = ab1, a2 = ab2;
+    const float* w = a.bpack + plan.wsdf_off + 4 * q;
+    const int ld = 16 * L.kt;
+    const float* Hl = a.H + (size_t)L.hpre * Pp + (size_t)pt * (16 * L.kt) + 4 * q;
+    const msdf_layer_t Lp = plan.layer[(nu - 2 == 1) ? 0 : nu - 2];
+    float* ABp = a.AB + (size_t)Lp.abpre * Pp + (size_t)pt * (16 * Lp.ot) + 4 * q;
+    const int ktl = L.kt - 1;
+    v4f hh[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) hh[t] = *(const v4f*)(Hl + 16 * (t < ktl ? t : ktl));     // every load before a store
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      v4f v = V4ZERO;
+      if (t < L.kt) {
+        const v4f w0 = *(const v4f*)(w + 16 * t), w1 = *(const v4f*)(w + ld + 16 * t), w2 = *(const v4f*)(w + 2 * ld + 16 * t);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float g = a0 * w0[r] + a1 * w1[r] + a2 * w2[r];
+          v[r] = (hh[t][r] > 0.f) ? g : 0.f;
+        }
+      }
+      in[t] = v;
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+      if (t < L.kt) *(v4f*)(ABp + 16 * t) = in[t];
+  }
   // ---- hidden layers, last to first
-  for (int u = nu - 1; u >= 2; --u) {
+  for (int u = (dot_out ? nu - 2 : nu - 1); u >= 2; --u) {
     const msdf_layer_t L = plan.layer[u];
     zero_tiles(acc);
     // the product yields h-bar of this layer's input = output of unit u-1 (u-1 == 1 means the first layer);

@@ -74,27 +74,42 @@ struct NoHooks {
   __device__ __forceinline__ void drain() {}
 };
 
-template <int KT_T, class Hooks>
+// PPC = pairs of out tiles per weight chunk: 1 for the wide products; narrow ones (K = 3, 5 tiles: the network
+// input layers, the misc block of the colour network) take several pairs per chunk -- a pair is then only 24 / 40
+// matrix instructions, too little work between two barriers.
+template <int KT_T, int PPC, class Hooks>
 __device__ __forceinline__ void gemm_tiles(v4f (&acc)[MT], const v4f (&in)[MT], const int OT, const int k_rt,
                                            const v4f* __restrict__ wsrc, v4f* lds, Hooks& hk) {
   constexpr bool DYN = (KT_T == 0);
   constexpr int KMAX = DYN ? MT : KT_T;
+  static_assert(PPC * CHUNK_OT * KMAX * 64 <= LDS_BUF_F4, "chunk larger than an LDS buffer");
   const int K = DYN ? k_rt : KT_T;
-  const int ch_f4 = CHUNK_OT * K * 64;
+  const int pair_f4 = CHUNK_OT * K * 64;
   const int lane = threadIdx.x & 63;
-  const int nchunks = (OT + CHUNK_OT - 1) / CHUNK_OT;
-  // Chunks are consumed from the LAST pair of out tiles down to the first.
-  chunk_issue<CHUNK_OT * KMAX>(wsrc + (size_t)(nchunks - 1) * ch_f4, lds + ((nchunks - 1) & 1) * LDS_BUF_F4, ch_f4);
+  const int npairs = (OT + CHUNK_OT - 1) / CHUNK_OT;
+  const int nchunks = (npairs + PPC - 1) / PPC;
+  constexpr int MAXPAIRS = (MT + 1) / 2;
+  constexpr int MAXCHUNKS = (MAXPAIRS + PPC - 1) / PPC;
+  // Chunks are consumed from the LAST pairs of out tiles down to the first.
+  {
+    const int p0 = (nchunks - 1) * PPC;
+    chunk_issue<PPC * CHUNK_OT * KMAX>(wsrc + (size_t)p0 * pair_f4, lds + ((nchunks - 1) & 1) * LDS_BUF_F4,
+                                       min(PPC, npairs - p0) * pair_f4);
+  }
   __syncthreads();
 #pragma unroll
-  for (int c = (MT + 1) / 2 - 1; c >= 0; --c) {
-    if (c < nchunks) {
-      const int buf = c & 1;
-      const bool has_next = (c > 0);
-      if (has_next)
-        chunk_issue<CHUNK_OT * KMAX>(wsrc + (size_t)(c - 1) * ch_f4, lds + (buf ^ 1) * LDS_BUF_F4, ch_f4);
+  for (int cc = MAXCHUNKS - 1; cc >= 0; --cc) {
+    if (cc < nchunks) {
+      const int buf = cc & 1;
+      if (cc > 0)
+        chunk_issue<PPC * CHUNK_OT * KMAX>(wsrc + (size_t)(cc - 1) * PPC * pair_f4, lds + (buf ^ 1) * LDS_BUF_F4,
+                                           PPC * pair_f4);
+#pragma unroll
+      for (int pl = PPC - 1; pl >= 0; --pl) {
+        const int c = cc * PPC + pl;          // pair of out tiles (2c, 2c + 1): a compile-time constant here
+        if (c < MAXPAIRS && c < npairs) {
       hk.pre(2 * c, 2 * c + 1);
-      const v4f* w0 = lds + buf * LDS_BUF_F4 + lane;
+      const v4f* w0 = lds + buf * LDS_BUF_F4 + pl * pair_f4 + lane;
       const v4f* w1 = w0 + K * 64;
       const int o0 = 2 * c;
       const int o1 = (2 * c + 1 < MT) ? 2 * c + 1 : 0;   // the dead pair of the last odd tile
@@ -167,6 +182,8 @@ __device__ __forceinline__ void gemm_tiles(v4f (&acc)[MT], const v4f (&in)[MT], 
         }
       }
       hk.post(o0, 2 * c + 1, 2 * c + 1 < MT && 2 * c + 1 < OT, acc[o0], acc[o1]);
+        }
+      }
       __syncthreads();
     }
   }
@@ -178,11 +195,11 @@ template <class Hooks>
 __device__ __forceinline__ void gemm_dispatch(const int kp, v4f (&acc)[MT], const v4f (&in)[MT], const int OT,
                                               const v4f* __restrict__ wsrc, v4f* lds, Hooks& hk) {
   switch (kp) {
-    case 3: gemm_tiles<3>(acc, in, OT, 3, wsrc, lds, hk); break;
-    case 5: gemm_tiles<5>(acc, in, OT, 5, wsrc, lds, hk); break;      // PE + hash-grid features
-    case 16: gemm_tiles<16>(acc, in, OT, 16, wsrc, lds, hk); break;
-    case 17: gemm_tiles<17>(acc, in, OT, 17, wsrc, lds, hk); break;
-    default: gemm_tiles<0>(acc, in, OT, kp, wsrc, lds, hk); break;
+    case 3: gemm_tiles<3, 4>(acc, in, OT, 3, wsrc, lds, hk); break;
+    case 5: gemm_tiles<5, 3>(acc, in, OT, 5, wsrc, lds, hk); break;      // PE + hash-grid features
+    case 16: gemm_tiles<16, 1>(acc, in, OT, 16, wsrc, lds, hk); break;
+    case 17: gemm_tiles<17, 1>(acc, in, OT, 17, wsrc, lds, hk); break;
+    default: gemm_tiles<0, 1>(acc, in, OT, kp, wsrc, lds, hk); break;
   }
   hk.drain();
 }

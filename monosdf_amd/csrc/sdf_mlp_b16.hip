@@ -58,10 +58,12 @@ __global__ void __launch_bounds__(256) msdf_pack_b16_kernel(const msdf_plan_t pl
       bpack[L.bias_off + i] = (row >= 0) ? flat_b[R.b_off + row] : 0.f;
     }
     if (l == plan.n_layers - 1 && plan.wsdf_off >= 0) {
-      const int sdf_row = rowmap[plan.sdf_slot];
-      for (int i = t0; i < 16 * L.kt; i += stride) {
-        const int col = colmap[i];
-        bpack[plan.wsdf_off + i] = (col >= 0) ? R.scale * W[(size_t)sdf_row * R.cols + col] : 0.f;
+      for (int rr = 0; rr < plan.out_rows; ++rr) {
+        const int row = rowmap[plan.sdf_slot + rr];
+        for (int i = t0; i < 16 * L.kt; i += stride) {
+          const int col = colmap[i];
+          bpack[plan.wsdf_off + rr * 16 * L.kt + i] = (col >= 0 && row >= 0) ? R.scale * W[(size_t)row * R.cols + col] : 0.f;
+        }
       }
     }
   }

@@ -183,6 +183,7 @@ def build_sdf_plan(w_shapes, skip_in, n_freqs, aux_cols, aux_active, feature_siz
         prev_ot, prev_out = L.ot, out
     P.hsum, P.qsum, P.absum = hpre, qpre, abpre
     P.wsdf_off = mp.bpack_f
+    P.out_rows = 1
     mp.bpack_f += 16 * P.layer[n - 1].kt
     P.mode, P.out_act = 0, 0
     mp.in0_tiles = in0_tiles
@@ -209,7 +210,6 @@ def build_color_plan(w_shapes, mode, n_freqs_view, feature_size, code_cols=0, ou
     P.e_tiles, P.aux_tiles, P.n_freqs, P.feat_tiles = 3, aux_tiles, n_freqs_view, feat_tiles
     P.mode = 1 if mode == 'idr' else 0
     P.out_act = 1 if out_relu else 0
-    P.wsdf_off = -1
     P.sdf_slot = 0
     out0 = w_shapes[0][0]
     row0 = _ident_map(out0, _ceil16(out0))
@@ -235,6 +235,12 @@ def build_color_plan(w_shapes, mode, n_freqs_view, feature_size, code_cols=0, ou
         hpre += 16 * L.kt
         prev_out, prev_ot = out, L.ot
     P.hsum, P.absum, P.qsum = hpre, abpre, 0
+    # the 3 colour rows of the output layer in input-slot order: the kernels form rgb as dot products over the last
+    # hidden activation (and its adjoint as an outer product) instead of a 16-row matrix product with 13 rows of zeros
+    assert w_shapes[n - 1][0] == 3
+    P.wsdf_off = mp.bpack_f
+    P.out_rows = 3
+    mp.bpack_f += 3 * 16 * P.layer[u].kt
     mp.misc_tiles = 3 + aux_tiles
     mp.lead = lead
     mp.kind = 'color'
