@@ -143,7 +143,7 @@ def pmc_traffic(entry, precision):
     """HBM bytes per launch of `entry` from the committed rocprofv3 --pmc summary (FETCH_SIZE x2 + WRITE_SIZE per the
     gfx950 note of MI355X_MICROARCH.md; scripts/pmc_sum.py) -> (bytes or None, file name or None)."""
     kernel = entry.replace('_if', '') + ('_k' if precision == 'fp32' else '_b16_k')
-    for name in ('r02_pmc_%s.json' % precision, 'r01_v8_pmc_%s.json' % precision):
+    for name in ('r03_pmc_%s.json' % precision, 'r02_pmc_%s.json' % precision, 'r01_v8_pmc_%s.json' % precision):
         path = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(path):
             row = json.load(open(path)).get(kernel)

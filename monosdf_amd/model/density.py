@@ -23,6 +23,9 @@ class LaplaceDensity(Density):
         self.register_buffer('beta_min', torch.tensor(beta_min), persistent=False)
 
     def density_func(self, sdf, beta=None):
+        # Device tensors only, first order only (ops.LaplaceDensityFunction raises on a CPU tensor): this package has
+        # no CPU or eager-PyTorch path on purpose -- a silent fallback would make "the HIP kernels ran" unverifiable.
+        # The reference's expression (density.py:21-27) also runs on the CPU and to any order of differentiation.
         if beta is None:
             beta = self.get_beta()
         if not torch.is_tensor(beta):
