@@ -363,3 +363,17 @@ def test_fullsize_sdf_volume_512():
     assert np.all(far_block == far_block[0, 0, 0])
     _record('configs[4] 512^3 SDF volume, coarse-to-fine, one GPU',
             {'seconds': dt, 'voxels': n ** 3, 'fraction_refined_to_finest_level': frac})
+
+
+def test_first_form_of_the_binned_scatter_still_runs():
+    """The count / scan / place / accumulate form stays in the library as the path for tables of more than 8,192 slices
+    per level; MSDF_HASH_SCATTER=1 (read once per process) selects it: the ray-ordered scatter test in a child process."""
+    import subprocess
+    import sys
+    env = dict(os.environ, MSDF_HASH_SCATTER='1')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', os.path.abspath(__file__), '-k',
+                        'ray_ordered or binned_scatter_equals'], cwd=root, env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert '2 passed' in r.stdout, r.stdout[-500:]
