@@ -10,13 +10,13 @@
 // unit 1 = first layer, misc columns; units 2.. = the remaining layers.
 #include "color_kernels.h"
 
-__global__ void __launch_bounds__(MLP_THREADS, 2)
+__global__ void __launch_bounds__(MLP_THREADS, MLP_WGS_PER_CU)
 msdf_color_forward_k(const msdf_plan_t plan, const ColorFwdArgs a) {
   extern __shared__ v4f lds[];
   color_forward_body<CoreF32>(plan, a, lds);
 }
 
-__global__ void __launch_bounds__(MLP_THREADS, 2)
+__global__ void __launch_bounds__(MLP_THREADS, MLP_WGS_PER_CU)
 msdf_color_backward_k(const msdf_plan_t plan, const ColorBwdArgs a) {
   extern __shared__ v4f lds[];
   color_backward_body<CoreF32>(plan, a, lds);

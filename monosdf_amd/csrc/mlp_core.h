@@ -18,9 +18,13 @@
 #include "../../include/monosdf_plan.h"
 
 #define MT MSDF_MAX_TILES   // 17
-#define MLP_THREADS 256
+#ifndef MLP_WAVES
+#define MLP_WAVES 4                      // waves per workgroup (all of them share every weight chunk)
+#endif
+#define MLP_THREADS (64 * MLP_WAVES)
 #define MLP_PTS_PER_WAVE 16
-#define MLP_PTS_PER_WG 64
+#define MLP_PTS_PER_WG (16 * MLP_WAVES)
+#define MLP_WGS_PER_CU (8 / MLP_WAVES)   // 256 registers per lane: two waves per SIMD
 #define CHUNK_OT 2                       // out tiles per LDS chunk
 #define LDS_BUF_F4 (CHUNK_OT * MT * 64)  // float4 per LDS buffer (34 KB)
 #define MLP_LDS_BYTES (2 * LDS_BUF_F4 * 16)
@@ -42,8 +46,8 @@ __device__ __forceinline__ void chunk_issue(const v4f* __restrict__ src, v4f* ds
   const int lane = threadIdx.x & 63;
   const int pieces = n_f4 >> 6;   // 1 KB pieces, one wave-instruction each
 #pragma unroll
-  for (int i = 0; i < (PIECES_MAX + 3) / 4; ++i) {
-    const int piece = wave + 4 * i;
+  for (int i = 0; i < (PIECES_MAX + MLP_WAVES - 1) / MLP_WAVES; ++i) {
+    const int piece = wave + MLP_WAVES * i;
     if (piece < pieces) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 64 + lane),
                                        (__attribute__((address_space(3))) void*)(dst + piece * 64), 16, 0, 0);

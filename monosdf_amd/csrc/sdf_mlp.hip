@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(256) msdf_pack_kernel(const msdf_plan_t plan,
   }
 }
 
-__global__ void __launch_bounds__(MLP_THREADS, 2)
+__global__ void __launch_bounds__(MLP_THREADS, MLP_WGS_PER_CU)
 msdf_sdf_forward_k(const msdf_plan_t plan, const v4f* __restrict__ wpack, const float* __restrict__ bpack,
                    const float* __restrict__ x, const float* __restrict__ aux, const int P,
                    const float clamp_radius, const float sphere_scale, float* __restrict__ sdf_out,
@@ -88,13 +88,13 @@ msdf_sdf_forward_k(const msdf_plan_t plan, const v4f* __restrict__ wpack, const 
   sdf_forward_body<CoreF32>(plan, wpack, bpack, x, aux, P, clamp_radius, sphere_scale, sdf_out, lds);
 }
 
-__global__ void __launch_bounds__(MLP_THREADS, 2)
+__global__ void __launch_bounds__(MLP_THREADS, MLP_WGS_PER_CU)
 msdf_sdf_fwd_grad_k(const msdf_plan_t plan, const FgArgs a) {
   extern __shared__ v4f lds[];
   sdf_fwd_grad_body<CoreF32>(plan, a, lds);
 }
 
-__global__ void __launch_bounds__(MLP_THREADS, 2)
+__global__ void __launch_bounds__(MLP_THREADS, MLP_WGS_PER_CU)
 msdf_sdf_backward_k(const msdf_plan_t plan, const BwArgs a) {
   extern __shared__ v4f lds[];
   sdf_backward_body<CoreF32>(plan, a, lds);
