@@ -19,7 +19,9 @@
 
 #define MT MSDF_MAX_TILES   // 17
 #ifndef MLP_WAVES
-#define MLP_WAVES 4                      // waves per workgroup (all of them share every weight chunk)
+#define MLP_WAVES 4                      // waves per workgroup (all of them share every weight chunk).  The library is
+                                         // built and tested with 4; 8 was a timing experiment of the fp32 kernels only
+                                         // (slower) and is not a supported configuration
 #endif
 #define MLP_THREADS (64 * MLP_WAVES)
 #define MLP_PTS_PER_WAVE 16
