@@ -57,6 +57,8 @@ def main():
                                            L, Sc, H, 1, P(dy), P(gg), P(ggrad), P(acc), n, P(ws), nbytes, st),
         'binned_fused': lambda: _lib.call('msdf_hash_encode_backward_fused', P(grad), P(grad2), P(x), P(offs), P(acc), B, 3,
                                           C, L, Sc, H, P(gg), n, P(ws), nbytes, st),
+        'binned_fused_out': lambda: _lib.call('msdf_hash_encode_backward_fused_out', P(grad), P(grad2), P(x), P(offs),
+                                              P(acc), B, 3, C, L, Sc, H, P(gg), n, P(ws), nbytes, st),
     }
     res = {'points': B, 'workspace_MB': nbytes / 1e6, 'pts': os.environ.get('PTS', 'rays')}
     only = os.environ.get('ONLY')
