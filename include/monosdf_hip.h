@@ -49,7 +49,7 @@ extern "C" {
 #define MSDF_ERR_LAUNCH 2
 #define MSDF_ERR_UNSUPPORTED 3
 
-#define MSDF_ABI_VERSION 5
+#define MSDF_ABI_VERSION 6
 int msdf_abi_version(void);
 
 /* ---- hash grid (reference: hashencoder/src/hashencoder.h:13-15) ----
@@ -226,7 +226,7 @@ typedef struct {
   const float* rgb;          /* [N,S,3] */
   const float* nrm;          /* [N,S,3] */
   const float* beta;         /* [1] = |beta| + beta_min */
-  const float* depth_scale;  /* [N] */
+  const float* depth_scale;  /* [N] with a pitch of depth_scale_stride floats (the z column of a [N,3] direction table) */
   int32_t N, S;
   int32_t white_bkgd;
   float bg0, bg1, bg2;
@@ -237,7 +237,8 @@ typedef struct {
   float* wsum;               /* [N] */
   const float* pose;         /* [N or 1, 4, 4] camera-to-world matrices or NULL (reference network.py:608-616) */
   int32_t pose_stride;       /* 16 per-ray poses, 0 one pose for all rays */
-  int32_t pad_;
+  int32_t depth_scale_stride; /* floats between the depth scales of consecutive rays (0 is read as 1) */
+  float* depth_vals;         /* [N,S] = z * depth_scale (reference network.py:572), or NULL */
 } msdf_composite_args_t;
 int msdf_composite_forward(const msdf_composite_args_t* args, void* stream);
 
@@ -264,9 +265,14 @@ typedef struct {
   float* g_beta_part;         /* [N] */
   const float* pose;          /* as in the forward */
   int32_t pose_stride;
-  int32_t pad_;
+  int32_t depth_scale_stride; /* as in the forward */
 } msdf_composite_bwd_args_t;
 int msdf_composite_backward(const msdf_composite_bwd_args_t* args, void* stream);
+
+/* LaplaceDensity.get_beta (reference model/density.py:28-30) and its adjoint, one launch each:
+ * out[0] = |beta_raw[0]| + beta_min;   g_raw[0] = sign(beta_raw[0]) * sum_i g_part[i]  (fixed summation order). */
+int msdf_beta_eff(const float* beta_raw, float beta_min, float* out, void* stream);
+int msdf_beta_grad(const float* beta_raw, const float* g_part, int n, float* g_raw, void* stream);
 
 /* ---- fused benchmark loss: value partials + all gradients in one pass ---- */
 typedef struct {
@@ -329,7 +335,7 @@ typedef struct {
   int32_t* new_pos;          /* [N, n_eval] their positions in z */
   float* pts;                /* [N * n_eval, 3] their 3-D points */
   float* beta;               /* [N] */
-  uint32_t* flags;           /* [2 * max_rounds], zeroed by the caller before the first round: flags[2r] = bits of the
+  uint32_t* flags;           /* [2 * max_rounds], zeroed by msdf_sampler_init: flags[2r] = bits of the
                                 batch's max beta after round r, flags[2r+1] = 1 when round r asks for another one.
                                 Rounds r > 0 return at once unless flags[2(r-1)+1] is set, so enqueueing more rounds
                                 than needed is harmless (reference: ray_sampler.py:125,179). */
@@ -349,6 +355,11 @@ typedef struct {
   float* dbg_dstar;          /* [N, m_max] or NULL: msdf_sampler_beta writes d* of the M-1 intervals (tests) */
   float* dbg_err0;           /* [N] or NULL: msdf_sampler_beta writes the error bound at beta0 (tests) */
   float* dbg_cdf;            /* [N, m_max] or NULL: msdf_sampler_resample writes the cdf it inverts (tests) */
+  const float* eik_u;        /* [N] U[0,1) or NULL: when eik_idx is NULL the eikonal sample of a ray is column
+                                floor(u * S) of its final set (reference: torch.randint, ray_sampler.py:254) */
+  int32_t eik_unit;          /* 1: eik_uniform holds U[0,1) values, mapped to (2u - 1) * bound here (reference:
+                                uniform_(-R, R), network.py:587); 0: it holds the points themselves */
+  int32_t pad_;
 } msdf_sampler_args_t;
 int msdf_sampler_init(const msdf_sampler_args_t* args, void* stream);
 int msdf_sampler_beta(const msdf_sampler_args_t* args, void* stream);

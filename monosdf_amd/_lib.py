@@ -82,7 +82,8 @@ class CompositeArgs(C.Structure):
                 ('N', C.c_int32), ('S', C.c_int32), ('white_bkgd', C.c_int32),
                 ('bg0', C.c_float), ('bg1', C.c_float), ('bg2', C.c_float),
                 ('weights', _P), ('rgb_values', _P), ('depth_values', _P), ('normal_map', _P),
-                ('wsum', _P), ('pose', _P), ('pose_stride', C.c_int32), ('pad_', C.c_int32)]
+                ('wsum', _P), ('pose', _P), ('pose_stride', C.c_int32), ('depth_scale_stride', C.c_int32),
+                ('depth_vals', _P)]
 
 
 class CompositeBwdArgs(C.Structure):
@@ -92,7 +93,7 @@ class CompositeBwdArgs(C.Structure):
                 ('N', C.c_int32), ('S', C.c_int32), ('white_bkgd', C.c_int32),
                 ('bg0', C.c_float), ('bg1', C.c_float), ('bg2', C.c_float),
                 ('g_sdf', _P), ('g_rgb', _P), ('g_nrm', _P), ('g_beta_part', _P),
-                ('pose', _P), ('pose_stride', C.c_int32), ('pad_', C.c_int32)]
+                ('pose', _P), ('pose_stride', C.c_int32), ('depth_scale_stride', C.c_int32)]
 
 
 class WnLayer(C.Structure):
@@ -124,7 +125,8 @@ class SamplerArgs(C.Structure):
                 ('pts', _P), ('beta', _P), ('flags', _P), ('jitter', _P), ('u_final', _P), ('final_z', _P),
                 ('extra_idx', _P), ('eik_idx', _P), ('z_out', _P), ('z_eik', _P), ('pts_out', _P),
                 ('eik_uniform', _P), ('nei_rand', _P), ('far_out', _P), ('rounds_out', _P),
-                ('dbg_dstar', _P), ('dbg_err0', _P), ('dbg_cdf', _P)]
+                ('dbg_dstar', _P), ('dbg_err0', _P), ('dbg_cdf', _P), ('eik_u', _P), ('eik_unit', C.c_int32),
+                ('pad_', C.c_int32)]
 
 
 _ERR = {1: 'invalid argument', 2: 'kernel launch failed', 3: 'unsupported configuration'}
@@ -163,6 +165,8 @@ _SIGNATURES = {
     'msdf_reduce': [_P, C.c_int, _P, _P, _P, _P],
     'msdf_composite_forward': [C.POINTER(CompositeArgs), _P],
     'msdf_composite_backward': [C.POINTER(CompositeBwdArgs), _P],
+    'msdf_beta_eff': [_P, C.c_float, _P, _P],
+    'msdf_beta_grad': [_P, _P, C.c_int, _P, _P],
     'msdf_probe_loss': [C.POINTER(ProbeLossArgs), _P],
     'msdf_sampler_init': [C.POINTER(SamplerArgs), _P],
     'msdf_sampler_beta': [C.POINTER(SamplerArgs), _P],
@@ -173,7 +177,7 @@ _SIGNATURES = {
     'msdf_laplace_density_backward': [_P, _P, C.c_int, C.c_int64, C.c_int, _P, _P, _P, _P],
 }
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib = None
 

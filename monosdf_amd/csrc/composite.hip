@@ -53,6 +53,7 @@ msdf_composite_forward_k(const CompositeArgs a) {
   const float beta = a.beta[0];
   const float* z = a.z + (size_t)ray * S;
   const float* sd = a.sdf + (size_t)ray * S;
+  const float dscale = a.depth_scale[(size_t)ray * (a.depth_scale_stride > 0 ? a.depth_scale_stride : 1)];
   float carry = 0.f;                 // inclusive sum of free energy of earlier chunks
   float r0 = 0.f, r1 = 0.f, r2 = 0.f, wz = 0.f, ws = 0.f, m0 = 0.f, m1 = 0.f, m2 = 0.f;
   for (int base = 0; base < S; base += 64) {
@@ -72,6 +73,7 @@ msdf_composite_forward_k(const CompositeArgs a) {
       const float trans = expf(-excl);
       w = alpha * trans;
       a.weights[(size_t)ray * S + i] = w;
+      if (a.depth_vals != nullptr) a.depth_vals[(size_t)ray * S + i] = z[i] * dscale;
       const float* c = a.rgb + ((size_t)ray * S + i) * 3;
       const float* n = a.nrm + ((size_t)ray * S + i) * 3;
       r0 += w * c[0]; r1 += w * c[1]; r2 += w * c[2];
@@ -92,7 +94,7 @@ msdf_composite_forward_k(const CompositeArgs a) {
     a.rgb_values[(size_t)ray * 3 + 0] = r0;
     a.rgb_values[(size_t)ray * 3 + 1] = r1;
     a.rgb_values[(size_t)ray * 3 + 2] = r2;
-    a.depth_values[ray] = a.depth_scale[ray] * (wz / (ws + 1e-8f));
+    a.depth_values[ray] = dscale * (wz / (ws + 1e-8f));
     if (a.pose != nullptr) {
       // rotate into the camera frame: out = R^T m, R = pose[:3,:3]
       const float* R = a.pose + (size_t)ray * a.pose_stride;
@@ -136,7 +138,7 @@ msdf_composite_backward_k(const CompositeBwdArgs a) {
   const float* z = a.z + (size_t)ray * S;
   const float* sd = a.sdf + (size_t)ray * S;
   const float ws = a.wsum[ray];
-  const float ds = a.depth_scale[ray];
+  const float ds = a.depth_scale[(size_t)ray * (a.depth_scale_stride > 0 ? a.depth_scale_stride : 1)];
   float gR0 = 0.f, gR1 = 0.f, gR2 = 0.f, gD = 0.f, gM0 = 0.f, gM1 = 0.f, gM2 = 0.f;
   if (a.g_rgb_values) {
     gR0 = a.g_rgb_values[(size_t)ray * 3 + 0];
@@ -235,6 +237,29 @@ msdf_composite_backward_k(const CompositeBwdArgs a) {
   }
   gbeta = wave_sum(gbeta);
   if (lane == 0) a.g_beta_part[ray] = gbeta;
+}
+
+// |beta| + beta_min, and its adjoint with the sum over the compositor's per-ray partials (one wave, fixed order)
+__global__ void msdf_beta_eff_k(const float* __restrict__ raw, const float beta_min, float* __restrict__ out) {
+  if (threadIdx.x == 0) out[0] = fabsf(raw[0]) + beta_min;
+}
+__global__ void __launch_bounds__(64)
+msdf_beta_grad_k(const float* __restrict__ raw, const float* __restrict__ part, const int n, float* __restrict__ g_raw) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) s += part[i];
+  s = wave_sum(s);
+  const float r = raw[0];
+  if (threadIdx.x == 0) g_raw[0] = ((r > 0.f) ? 1.f : (r < 0.f) ? -1.f : 0.f) * s;
+}
+extern "C" int msdf_beta_eff(const float* beta_raw, float beta_min, float* out, void* stream) {
+  if (beta_raw == nullptr || out == nullptr) return MSDF_ERR_ARG;
+  msdf_beta_eff_k<<<1, 64, 0, (hipStream_t)stream>>>(beta_raw, beta_min, out);
+  return msdf_check_launch();
+}
+extern "C" int msdf_beta_grad(const float* beta_raw, const float* g_part, int n, float* g_raw, void* stream) {
+  if (beta_raw == nullptr || g_raw == nullptr || n < 0 || (n > 0 && g_part == nullptr)) return MSDF_ERR_ARG;
+  msdf_beta_grad_k<<<1, 64, 0, (hipStream_t)stream>>>(beta_raw, g_part, n, g_raw);
+  return msdf_check_launch();
 }
 
 extern "C" int msdf_composite_forward(const msdf_composite_args_t* a, void* stream) {

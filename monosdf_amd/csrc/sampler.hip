@@ -60,6 +60,9 @@ __global__ void __launch_bounds__(64 * SMP_WAVES) smp_init_k(const SmpArgs a) {
   const int ray = blockIdx.x * SMP_WAVES + (threadIdx.x >> 6);
   if (ray >= a.N) return;
   const int lane = lane_id();
+  // the round flags start at zero: no launch of this call reads them before the round kernels behind this one
+  if (ray == 0 && a.flags != nullptr)
+    for (int i = lane; i < 2 * a.max_rounds; i += 64) a.flags[i] = 0u;
   const int n = a.n_eval;
   const float o0 = a.ray_o[ray * 3 + 0], o1 = a.ray_o[ray * 3 + 1], o2 = a.ray_o[ray * 3 + 2];
   const float d0 = a.ray_d[ray * 3 + 0], d1 = a.ray_d[ray * 3 + 1], d2 = a.ray_d[ray * 3 + 2];
@@ -371,7 +374,8 @@ __global__ void __launch_bounds__(64 * SMP_WAVES) smp_finish_k(const SmpArgs a) 
   }
   smp_sync();
   if (lane == 0) {
-    const int idx = (a.eik_idx != nullptr) ? (int)a.eik_idx[ray] : 0;
+    const int idx = (a.eik_idx != nullptr) ? (int)a.eik_idx[ray]
+                    : (a.eik_u != nullptr) ? min(S - 1, (int)(a.eik_u[ray] * (float)S)) : 0;
     const float ze = sorted[idx];
     if (a.z_eik != nullptr) a.z_eik[ray] = ze;
     if (a.pts_out != nullptr && a.eik_uniform != nullptr) {
@@ -380,7 +384,8 @@ __global__ void __launch_bounds__(64 * SMP_WAVES) smp_finish_k(const SmpArgs a) 
       const float od[3] = {o0 + ze * d0, o1 + ze * d1, o2 + ze * d2};
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const float u = a.eik_uniform[(size_t)ray * 3 + c];
+        float u = a.eik_uniform[(size_t)ray * 3 + c];
+        if (a.eik_unit) u = (2.0f * u - 1.0f) * a.bound;
         e[((size_t)ray) * 3 + c] = u;
         e[((size_t)a.N + ray) * 3 + c] = od[c];
         e[((size_t)2 * a.N + ray) * 3 + c] = u + (a.nei_rand[(size_t)ray * 3 + c] - 0.5f) * 0.01f;

@@ -21,6 +21,7 @@ class LaplaceDensity(Density):
     def __init__(self, params_init={}, beta_min=0.0001):
         super().__init__(params_init=params_init)
         self.register_buffer('beta_min', torch.tensor(beta_min), persistent=False)
+        self.beta_min_f = float(beta_min)          # the same constant for kernel arguments (no device read)
 
     def density_func(self, sdf, beta=None):
         # Device tensors only, first order only (ops.LaplaceDensityFunction raises on a CPU tensor): this package has

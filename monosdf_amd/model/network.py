@@ -398,7 +398,9 @@ class MonoSDFNetwork(nn.Module):
         device = ray_dirs.device
         noise = self._noise or {}
         net = self.implicit_network
-        beta = self.density.get_beta()          # once per pass: the sampler and the compositor use the same value
+        # |beta| + beta_min once per pass, ONE launch: the sampler and the compositor use the same value; the gradient
+        # reaches density.beta through the compositor's beta_raw argument (no abs / add / sgn / mul launches of autograd)
+        beta = ops.effective_beta(self.density.beta, self.density.beta_min_f)
         net.share(device)
         self.rendering_network.share(device)
         try:
@@ -428,9 +430,9 @@ class MonoSDFNetwork(nn.Module):
                                                   if_pixel_input=if_pixel_input, samples_per_ray=S)['rgb']
                 rgb = rgb_flat.reshape(-1, S, 3)
                 # the compositor also rotates the normal map into the camera frame (R^T, reference 608-616)
-                weights, rgb_values, depth_values, normal_map = ops.CompositeFunction.apply(
+                weights, rgb_values, depth_values, normal_map, depth_vals = ops.CompositeFunction.apply(
                     z_vals, sdf, rgb_flat, gradients_sdf, beta, depth_scale, self.white_bkgd,
-                    self._bg_list(), pose)
+                    self._bg_list(), pose, self.density.beta, True)
                 if attempt == 0 or attempt == K or self.ray_sampler.confirm():
                     break
         finally:
@@ -442,7 +444,7 @@ class MonoSDFNetwork(nn.Module):
             'rgb_values': rgb_values,
             'depth_values': depth_values,
             'z_vals': z_vals,
-            'depth_vals': z_vals * depth_scale,
+            'depth_vals': depth_vals,
             'sdf': sdf.reshape(z_vals.shape),
             'weights': weights,
         }

@@ -218,13 +218,16 @@ class ErrorBoundSampler(RaySampler):
         new_pos = torch.empty(N, n_eval, device=dev, dtype=torch.int32)
         pts = torch.empty(N * n_eval, 3, **f32)
         beta = torch.empty(N, **f32)
-        flags = torch.zeros(2 * K, device=dev, dtype=torch.int32)
+        flags = torch.empty(2 * K, device=dev, dtype=torch.int32)        # zeroed by msdf_sampler_init
         final_z = torch.empty(N, n_final, **f32)
-        jitter = u_final = nei_drawn = None
+        jitter = u_final = nei_drawn = eik_u_drawn = eik_unit_drawn = None
         if training:
-            # one launch for every U[0,1) draw of the call (stratified jitter, inverse-CDF u, neighbour jitter)
-            need = [k for k in ('jitter', 'final_u', 'nei_rand') if noise.get(k) is None]
-            sizes = {'jitter': N * n_eval, 'final_u': N * n_final, 'nei_rand': 6 * N if want_points else 0}
+            # ONE launch for every random draw of the call: stratified jitter, inverse-CDF u, neighbour jitter, the
+            # eikonal sample's column (floor(u S): the reference's randint, ray_sampler.py:254) and the uniform
+            # eikonal points ((2u - 1) R inside the finish kernel: the reference's uniform_(-R, R), network.py:587)
+            need = [k for k in ('jitter', 'final_u', 'nei_rand', 'eik_idx', 'eik_uniform') if noise.get(k) is None]
+            sizes = {'jitter': N * n_eval, 'final_u': N * n_final, 'nei_rand': 6 * N if want_points else 0,
+                     'eik_idx': N, 'eik_uniform': 3 * N if want_points else 0}
             pool = torch.rand(sum(sizes[k] for k in need), **f32) if need else None
             drawn, off = {}, 0
             for k in need:
@@ -235,6 +238,7 @@ class ErrorBoundSampler(RaySampler):
             u_final = noise.get('final_u')
             u_final = drawn['final_u'].view(N, n_final) if u_final is None else u_final.to(**f32).contiguous()
             nei_drawn = drawn.get('nei_rand')
+            eik_u_drawn, eik_unit_drawn = drawn.get('eik_idx'), drawn.get('eik_uniform')
         a = _lib.SamplerArgs()
         a.ray_o, a.ray_d, a.N = cam_loc.data_ptr(), ray_dirs.data_ptr(), N
         a.m_max, a.n_eval, a.n_final, a.n_extra = m_max, n_eval, n_final, n_extra
@@ -257,12 +261,17 @@ class ErrorBoundSampler(RaySampler):
             GPU is still busy with the first round, so that after a host sync only the launch is left."""
             nonlocal z_out, z_eik, x_all, extra_idx, eik_idx
             eik_idx = noise.get('eik_idx')
-            if eik_idx is None:
-                eik_idx = torch.randint(S, (N,), device=dev)
-            eik_idx = eik_idx.to(device=dev, dtype=torch.int64).contiguous()
+            a.eik_u, a.eik_unit = None, 0
+            if eik_idx is None and eik_u_drawn is not None:
+                a.eik_idx, a.eik_u = None, eik_u_drawn.data_ptr()        # the column is floor(u S), formed in the kernel
+            else:
+                if eik_idx is None:
+                    eik_idx = torch.randint(S, (N,), device=dev)
+                eik_idx = eik_idx.to(device=dev, dtype=torch.int64).contiguous()
+                a.eik_idx = eik_idx.data_ptr()
             z_out = torch.empty(N, S, **f32)
             z_eik = torch.empty(N, 1, **f32)
-            a.eik_idx, a.z_out, a.z_eik, a.pts_out = eik_idx.data_ptr(), z_out.data_ptr(), z_eik.data_ptr(), None
+            a.z_out, a.z_eik, a.pts_out = z_out.data_ptr(), z_eik.data_ptr(), None
             if want_points:
                 n_eik = 4 * N if training else 0
                 x_all = torch.empty(N * S + n_eik, 3, **f32)
@@ -270,8 +279,11 @@ class ErrorBoundSampler(RaySampler):
                 if training:
                     R = self.scene_bounding_sphere
                     eik_uniform = noise.get('eik_uniform')
-                    eik_uniform = (torch.empty(N, 3, **f32).uniform_(-R, R) if eik_uniform is None
-                                   else eik_uniform.to(**f32).contiguous())
+                    if eik_uniform is None and eik_unit_drawn is not None and eik_unit_drawn.numel() == 3 * N:
+                        eik_uniform, a.eik_unit = eik_unit_drawn.view(N, 3), 1       # U[0,1): scaled to the cube in the kernel
+                    else:
+                        eik_uniform = (torch.empty(N, 3, **f32).uniform_(-R, R) if eik_uniform is None
+                                       else eik_uniform.to(**f32).contiguous())
                     nei = noise.get('nei_rand')
                     nei = nei_drawn.view(2 * N, 3) if nei is None else nei.to(**f32).contiguous()
                     a.eik_uniform, a.nei_rand = eik_uniform.data_ptr(), nei.data_ptr()

@@ -121,7 +121,9 @@ class FusedMlp:
             prog = planlib.balanced_program(build, self.mp, P_pad)
             rules_dev = torch.from_numpy(prog.rules_bytes()).to(self.device)
             wg_map = torch.from_numpy(prog.wg_map()).to(self.device)
-            self._wgrad_cache[key] = dict(prog=prog, rules=rules_dev, wg_map=wg_map, items={})
+            # when the reduce rules store to every gradient element the flat buffer needs no zero fill
+            full = prog.writes_every_element(self.mp.n_w + self.mp.n_b, self.mp.maps_np)
+            self._wgrad_cache[key] = dict(prog=prog, rules=rules_dev, wg_map=wg_map, items={}, full=full)
         return self._wgrad_cache[key]
 
     def run_wgrad(self, P_pad, base_addr, defer=False):
@@ -138,7 +140,8 @@ class FusedMlp:
             ent['items'][key] = torch.from_numpy(prog.items_bytes(addr)).to(self.device)
         items_dev = ent['items'][key]
         part = torch.empty(prog.part_f + 64, device=self.device, dtype=torch.float32)
-        grad = torch.zeros(self.mp.n_w + self.mp.n_b, device=self.device, dtype=torch.float32)
+        alloc = torch.empty if ent['full'] else torch.zeros
+        grad = alloc(self.mp.n_w + self.mp.n_b, device=self.device, dtype=torch.float32)
         wg_map = ent['wg_map']
         held = list(base_addr.values())
 
@@ -593,10 +596,16 @@ class ColorMlpFunction(torch.autograd.Function):
 # compositor
 # ---------------------------------------------------------------------------
 class CompositeFunction(torch.autograd.Function):
-    """(z, sdf, rgb, normals, beta, depth_scale) -> weights, rgb_values, depth_values, normal_map."""
+    """(z, sdf, rgb, normals, beta, depth_scale) -> weights, rgb_values, depth_values, normal_map [, depth_vals].
+
+    beta_raw / beta_min (optional): `beta` is then |beta_raw| + beta_min formed by effective_beta() and the gradient
+    goes to `beta_raw` directly -- sign(beta_raw) times the sum of the kernel's per-ray partials in ONE launch -- instead
+    of through abs / add / sum / sgn / mul launches of autograd.  want_depth_vals: also z * depth_scale per sample
+    (the reference's `depth_vals`), written by the same kernel."""
 
     @staticmethod
-    def forward(ctx, z, sdf, rgb, nrm, beta, depth_scale, white_bkgd, bg, pose=None):
+    def forward(ctx, z, sdf, rgb, nrm, beta, depth_scale, white_bkgd, bg, pose=None, beta_raw=None,
+                want_depth_vals=False):
         ctx.set_materialize_grads(False)      # unused outputs (e.g. `weights`) arrive as None, not as zero fills
         z = _need_cuda(z.detach(), 'z_vals')
         N, S = z.shape
@@ -605,16 +614,28 @@ class CompositeFunction(torch.autograd.Function):
         rgb = _need_cuda(rgb.detach(), 'rgb').reshape(N, S, 3)
         nrm = _need_cuda(nrm.detach(), 'normals').reshape(N, S, 3)
         beta = _need_cuda(beta.detach(), 'beta').reshape(1)
-        depth_scale = _need_cuda(depth_scale.detach(), 'depth_scale').reshape(N)
+        ctx.beta_shape = None if beta_raw is None else beta_raw.shape
+        raw = beta if beta_raw is None else _need_cuda(beta_raw.detach(), 'beta').reshape(1)
+        # one scale per ray: a dense [N] vector, or a column of a [N, k] table read in place (pitch k floats)
+        depth_scale = depth_scale.detach()
+        if depth_scale.dim() == 2 and depth_scale.shape[0] == N and depth_scale.shape[1] == 1 and N > 0 \
+                and depth_scale.is_cuda and depth_scale.dtype == torch.float32 and depth_scale.stride(1) == 1:
+            ds_stride = int(depth_scale.stride(0))
+        else:
+            depth_scale = _need_cuda(depth_scale, 'depth_scale').reshape(N)
+            ds_stride = 1
         dev = z.device
         weights = torch.empty(N, S, device=dev)
         rgb_values = torch.empty(N, 3, device=dev)
         depth_values = torch.empty(N, 1, device=dev)
         normal_map = torch.empty(N, 3, device=dev)
         wsum = torch.empty(max(N, 1), device=dev)
+        depth_vals = torch.empty(N, S, device=dev) if want_depth_vals else None
         a = _lib.CompositeArgs()
         a.z, a.sdf, a.rgb, a.nrm = z.data_ptr(), sdf.data_ptr(), rgb.data_ptr(), nrm.data_ptr()
         a.beta, a.depth_scale = beta.data_ptr(), depth_scale.data_ptr()
+        a.depth_scale_stride = ds_stride
+        a.depth_vals = depth_vals.data_ptr() if depth_vals is not None else None
         a.N, a.S, a.white_bkgd = N, S, 1 if white_bkgd else 0
         a.bg0, a.bg1, a.bg2 = [float(v) for v in bg]
         a.weights, a.rgb_values, a.depth_values = weights.data_ptr(), rgb_values.data_ptr(), depth_values.data_ptr()
@@ -629,14 +650,17 @@ class CompositeFunction(torch.autograd.Function):
             a.pose, a.pose_stride = None, 0
         ctx.has_pose, ctx.pose_stride = a.pose is not None, a.pose_stride
         _lib.call('msdf_composite_forward', C.byref(a), _lib.stream_ptr())
-        ctx.save_for_backward(z, sdf, rgb, nrm, beta, depth_scale, weights, wsum, depth_values, pose)
-        ctx.white_bkgd, ctx.bg = white_bkgd, [float(v) for v in bg]
+        ctx.save_for_backward(z, sdf, rgb, nrm, beta, depth_scale, weights, wsum, depth_values, pose, raw)
+        ctx.white_bkgd, ctx.bg, ctx.ds_stride = white_bkgd, [float(v) for v in bg], ds_stride
+        if want_depth_vals:
+            ctx.mark_non_differentiable(depth_vals)       # z_vals carries no gradient (the sampler runs under no_grad)
+            return weights, rgb_values, depth_values, normal_map, depth_vals
         return weights, rgb_values, depth_values, normal_map
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, g_w, g_rgbv, g_depth, g_nmap):
-        z, sdf, rgb, nrm, beta, depth_scale, weights, wsum, depth_values, pose = ctx.saved_tensors
+    def backward(ctx, g_w, g_rgbv, g_depth, g_nmap, g_dvals=None):
+        z, sdf, rgb, nrm, beta, depth_scale, weights, wsum, depth_values, pose, raw = ctx.saved_tensors
         N, S = z.shape
         dev = z.device
         cont = lambda t: None if t is None else t.contiguous()
@@ -658,10 +682,27 @@ class CompositeFunction(torch.autograd.Function):
         b.g_sdf, b.g_rgb, b.g_nrm, b.g_beta_part = g_sdf.data_ptr(), g_rgb.data_ptr(), g_nrm.data_ptr(), \
             g_beta_part.data_ptr()
         b.pose, b.pose_stride = (pose.data_ptr() if ctx.has_pose else None), ctx.pose_stride
+        b.depth_scale_stride = ctx.ds_stride
         _lib.call('msdf_composite_backward', C.byref(b), _lib.stream_ptr())
-        g_beta = g_beta_part[:N].sum().reshape(beta.shape)
         sh = ctx.in_shapes
-        return (None, g_sdf.reshape(sh[0]), g_rgb.reshape(sh[1]), g_nrm.reshape(sh[2]), g_beta, None, None, None, None)
+        if ctx.beta_shape is not None:
+            # d loss / d beta_raw = sign(beta_raw) * sum over rays, one launch (fixed summation order)
+            g_raw = torch.empty(1, device=dev)
+            _lib.call('msdf_beta_grad', _lib.ptr(raw), _lib.ptr(g_beta_part), N, _lib.ptr(g_raw), _lib.stream_ptr())
+            return (None, g_sdf.reshape(sh[0]), g_rgb.reshape(sh[1]), g_nrm.reshape(sh[2]), None, None, None, None, None,
+                    g_raw.reshape(ctx.beta_shape), None)
+        g_beta = g_beta_part[:N].sum().reshape(beta.shape)
+        return (None, g_sdf.reshape(sh[0]), g_rgb.reshape(sh[1]), g_nrm.reshape(sh[2]), g_beta, None, None, None, None,
+                None, None)
+
+
+def effective_beta(beta_raw, beta_min):
+    """|beta_raw| + beta_min as a detached device tensor [1] (LaplaceDensity.get_beta, reference density.py:28-30) in one
+    launch; the gradient path is CompositeFunction's beta_raw argument."""
+    raw = _need_cuda(beta_raw.detach(), 'beta').reshape(1)
+    out = torch.empty(1, device=raw.device, dtype=torch.float32)
+    _lib.call('msdf_beta_eff', _lib.ptr(raw), float(beta_min), _lib.ptr(out), _lib.stream_ptr())
+    return out
 
 
 # ---------------------------------------------------------------------------

@@ -320,6 +320,23 @@ class WgradProgram:
         r.rowmap_off, r.colmap_off, r.dst_ld, r.fixed_row, r.scale = rowmap_off, colmap_off, dst_ld, fixed_row, scale
         self.rules.append(r)
 
+    def writes_every_element(self, n_total, maps_np):
+        """True when the reduce rules together store to every element of the flat gradient [n_total] (then the caller
+        need not zero-fill it first).  Mirrors msdf_reduce_k's addressing: dst_off + row * dst_ld + col, rows / columns
+        through the slot maps, padding slots (-1) skipped."""
+        hit = np.zeros(n_total, dtype=bool)
+        for r in self.rules:
+            rows = maps_np[r.rowmap_off:r.rowmap_off + r.wx] if r.rowmap_off >= 0 else np.full(r.wx, r.fixed_row)
+            cols = maps_np[r.colmap_off:r.colmap_off + r.wy] if r.colmap_off >= 0 else np.zeros(r.wy, dtype=np.int64)
+            rows, cols = rows[rows >= 0].astype(np.int64), cols[cols >= 0].astype(np.int64)
+            if rows.size == 0 or cols.size == 0:
+                continue
+            idx = (r.dst_off + rows[:, None] * r.dst_ld + cols[None, :]).reshape(-1)
+            if idx.min() < 0 or idx.max() >= n_total:
+                return False
+            hit[idx] = True
+        return bool(hit.all())
+
     def rules_bytes(self):
         return np.frombuffer(b''.join(bytes(r) for r in self.rules), dtype=np.uint8).copy()
 
