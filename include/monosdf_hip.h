@@ -274,7 +274,7 @@ int msdf_composite_backward(const msdf_composite_bwd_args_t* args, void* stream)
 int msdf_beta_eff(const float* beta_raw, float beta_min, float* out, void* stream);
 int msdf_beta_grad(const float* beta_raw, const float* g_part, int n, float* g_raw, void* stream);
 
-/* ---- fused benchmark loss: value partials + all gradients in one pass ---- */
+/* ---- fused benchmark loss: the value and all gradients in one launch of one workgroup ---- */
 typedef struct {
   const float* rgb;      /* [N,3] rgb_values */
   const float* nrm;      /* [N,3] normal_map */
@@ -284,7 +284,7 @@ typedef struct {
   int32_t N, M;
   float w_normal, w_depth, w_eik, w_smooth;
   float* g_rgb; float* g_nrm; float* g_depth; float* g_g1; float* g_g2;   /* d loss / d input */
-  float* partial;        /* [ceil(max(N,M)/256)] per-block loss partial sums */
+  float* partial;        /* [1] the loss value */
 } msdf_probe_loss_args_t;
 int msdf_probe_loss(const msdf_probe_loss_args_t* args, void* stream);
 

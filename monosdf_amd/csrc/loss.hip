@@ -2,16 +2,20 @@
 //   L = mean|rgb| + w_n mean|normal| + w_d mean(depth) + w_e mean((|g1|-1)^2) + w_s mean|n1 - n2|,
 //   n_i = g_i / (|g_i| + 1e-5),  g1 = grad_theta, g2 = grad_theta_nei.
 // Every term is a mean of per-row functions, so each row's gradient is local; the loss value is
-// reduced per block and summed on the host side of the stream (deterministic).
+// reduced inside the one workgroup in a fixed order (deterministic): `partial[0]` is the loss.
 // msdf_monosdf_loss below is the reference's training loss.
 #include "common.h"
 
 __device__ __forceinline__ float sgnf(const float v) { return (v > 0.f) ? 1.f : (v < 0.f) ? -1.f : 0.f; }
 
-__global__ void __launch_bounds__(256)
+// ONE workgroup of 1,024 threads (the batch is ~1k rays and 2k eikonal points): the loss value leaves the kernel
+// complete -- thread-serial partial sums, wave butterflies, the 16 wave sums added in order -- so that no reduction
+// launch follows it.
+__global__ void __launch_bounds__(1024)
 msdf_probe_loss_k(const msdf_probe_loss_args_t a) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
   float part = 0.f;
+  const int n_rows = a.N > a.M ? a.N : a.M;
+  for (int i = threadIdx.x; i < n_rows; i += 1024) {
   if (i < a.N) {
     const float inv3n = 1.0f / (3.0f * a.N);
 #pragma unroll
@@ -53,13 +57,19 @@ msdf_probe_loss_k(const msdf_probe_loss_args_t a) {
       a.g_g2[(size_t)i * 3 + c] = -k * j2;
     }
   }
-  // block reduction of the loss value
-  __shared__ float red[4];
+  }
+  // reduction of the loss value over the workgroup, fixed order
+  __shared__ float red[16];
 #pragma unroll
   for (int dlt = 32; dlt >= 1; dlt >>= 1) part += __shfl_xor(part, dlt, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
   __syncthreads();
-  if (threadIdx.x == 0) a.partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w];
+    a.partial[0] = t;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -233,7 +243,6 @@ extern "C" int msdf_monosdf_loss(const msdf_monosdf_loss_args_t* a, void* stream
 
 extern "C" int msdf_probe_loss(const msdf_probe_loss_args_t* a, void* stream) {
   if (a == nullptr || a->N < 1 || a->M < 0) return MSDF_ERR_ARG;
-  const int n = a->N > a->M ? a->N : a->M;
-  msdf_probe_loss_k<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(*a);
+  msdf_probe_loss_k<<<1, 1024, 0, (hipStream_t)stream>>>(*a);
   return msdf_check_launch();
 }

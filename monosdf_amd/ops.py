@@ -876,7 +876,7 @@ class ProbeLossFunction(torch.autograd.Function):
         for t, n in zip((rgb, nrm, depth, g1, g2), sizes):
             outs.append(flat[off:off + n].view(t.shape))
             off += n
-        partial = torch.empty((max(N, M) + 255) // 256, device=dev, dtype=torch.float32)
+        partial = torch.empty(1, device=dev, dtype=torch.float32)        # the complete loss value (one workgroup)
         a = _lib.ProbeLossArgs()
         a.rgb, a.nrm, a.depth, a.g1, a.g2 = [t.data_ptr() for t in (rgb, nrm, depth, g1, g2)]
         a.N, a.M = N, M
@@ -886,7 +886,7 @@ class ProbeLossFunction(torch.autograd.Function):
         _lib.call('msdf_probe_loss', C.byref(a), _lib.stream_ptr())
         ctx.save_for_backward(flat)
         ctx.sizes, ctx.shapes = sizes, [t.shape for t in (rgb, nrm, depth, g1, g2)]
-        return partial.sum()
+        return partial.reshape(())
 
     @staticmethod
     @torch.autograd.function.once_differentiable
