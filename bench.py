@@ -45,7 +45,8 @@ N_BATCHES = 8          # ray batches cycled through by the timed steps
 TIMED = {'msdf_sdf_forward_if', 'msdf_sdf_fwd_grad', 'msdf_sdf_backward', 'msdf_wgrad', 'msdf_reduce',
          'msdf_color_forward', 'msdf_color_backward', 'msdf_hash_encode_forward', 'msdf_hash_encode_backward',
          'msdf_hash_encode_second_backward', 'msdf_hash_encode_backward_ws', 'msdf_hash_encode_second_backward_ws',
-         'msdf_hash_encode_backward_fused', 'msdf_hash_encode_backward_fused_out'}
+         'msdf_hash_encode_backward_fused', 'msdf_hash_encode_backward_fused_out', 'msdf_hash_node_forward',
+         'msdf_hash_node_input_gradient', 'msdf_hash_node_second_grad', 'msdf_hash_node_scatter'}
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 
 
@@ -159,7 +160,12 @@ def pmc_traffic_grid(entry):
     kernels = {'msdf_hash_encode_forward': ['void hg_forward_kernel'],
                'msdf_hash_encode_backward': ['void hg_backward_input_kernel'],
                'msdf_hash_encode_second_backward_ws': ['void hg_second_backward_grad_kernel'],
-               'msdf_hash_encode_backward_fused_out': ['void hb2_place_k', 'void hb2_accumulate_k']}
+               'msdf_hash_encode_backward_fused_out': ['void hb2_place_k', 'void hb2_accumulate_k'],
+               # node forms of the same kernels (ops.GridSdfFunction, the sampler's evaluations)
+               'msdf_hash_node_forward': ['void hg_node_forward_kernel'],
+               'msdf_hash_node_input_gradient': ['void hg_node_input_gradient_kernel'],
+               'msdf_hash_node_second_grad': ['void hg_node_second_grad_kernel'],
+               'msdf_hash_node_scatter': ['void hb2_place_k', 'void hb2_accumulate_k']}
     path = os.path.join(ROOT, 'profiles', 'r03_pmc_grid.json')
     if not os.path.exists(path) or entry not in kernels:
         return None, None
@@ -177,10 +183,10 @@ def grid_report(args, kern, dt, world, rounds, loss, sampler):
     """configs[2]: roofline of the hash-grid entry points against HBM (SURVEY.md 8(d) bytes per point)."""
     P_main, P_smp = N_RAYS * 98 + 4 * N_RAYS, N_RAYS * 128
     # bytes per call of each entry point, summed over its launches in one step
+    n_fwd = lambda name: kern.get(name, {}).get('launches_per_step', 1.0 + rounds)
     per_step_bytes = {
         # main pass (with dy_dx) + one sampler evaluation (no dy_dx) per further launch of the step
-        'msdf_hash_encode_forward': 1548.0 * P_main + 1164.0 * P_smp * max(
-            0.0, kern.get('msdf_hash_encode_forward', {}).get('launches_per_step', 1.0 + rounds) - 1.0),
+        'msdf_hash_encode_forward': 1548.0 * P_main + 1164.0 * P_smp * max(0.0, n_fwd('msdf_hash_encode_forward') - 1.0),
         'msdf_hash_encode_backward': 524.0 * P_main + 1164.0 * P_main,            # input-bwd (d/dx) + grid-bwd
         'msdf_hash_encode_second_backward': (524.0 + 1176.0) * P_main,
         # the fused node (ops.GridSdfFunction): d/dx only; grad_grad only; both embedding scatters in one pass
@@ -188,6 +194,11 @@ def grid_report(args, kern, dt, world, rounds, loss, sampler):
         'msdf_hash_encode_second_backward_ws': 524.0 * P_main,
         'msdf_hash_encode_backward_fused': (1164.0 + 1176.0) * P_main,
         'msdf_hash_encode_backward_fused_out': (1164.0 + 1176.0) * P_main,
+        # node forms: the same kernels' bytes; x01 / layout / scaling inside add nothing algorithmic
+        'msdf_hash_node_forward': 1548.0 * P_main + 1164.0 * P_smp * max(0.0, n_fwd('msdf_hash_node_forward') - 1.0),
+        'msdf_hash_node_input_gradient': 524.0 * P_main,
+        'msdf_hash_node_second_grad': 524.0 * P_main,
+        'msdf_hash_node_scatter': (1164.0 + 1176.0) * P_main,
     }
     if 'msdf_hash_encode_backward_fused' in kern or 'msdf_hash_encode_backward_fused_out' in kern:
         # there the plain entry point computes d/dx only

@@ -49,7 +49,7 @@ extern "C" {
 #define MSDF_ERR_LAUNCH 2
 #define MSDF_ERR_UNSUPPORTED 3
 
-#define MSDF_ABI_VERSION 6
+#define MSDF_ABI_VERSION 7
 int msdf_abi_version(void);
 
 /* ---- hash grid (reference: hashencoder/src/hashencoder.h:13-15) ----
@@ -98,6 +98,32 @@ int msdf_hash_encode_backward_fused_out(const float* grad_first, const float* gr
                                         const int* offsets, float* grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
                                         uint32_t L, float S, uint32_t H, const float* grad_grad_inputs,
                                         uint64_t n_entries, void* workspace, uint64_t workspace_bytes, void* stream);
+
+/* "Node" forms for the fused grid node (no counterpart in the reference: it runs these steps as tensor expressions
+ * around its three kernels).  Points in world coordinates: x01 = (x / divide_factor + 1) / 2 is formed inside, rounded
+ * as the tensor expression rounds it, and returned in x01_out (may be NULL).  Features and the gradients with respect
+ * to them: pitch == 0 level-major [L, B, C] (the hash kernels' own, coalesced layout); pitch > 0 point-major rows of
+ * `pitch` floats ([B, pitch], level l channel c at column l*C + c, columns >= L*C written as zeros) -- what the fused
+ * SDF kernels read / write.  dy_dx is level-major [L, B, 3C] (NULL: none).
+ * msdf_hash_transpose: [L, B, C] <-> [B, pitch] through LDS tiles (both sides coalesced), one or two tensors per launch.
+ * msdf_hash_node_input_gradient: inout[b,:] += scale * sum_{l,c} g(b,l,c) * dy_dx[l,b,:,c].
+ * msdf_hash_node_second_grad: gg_out[b,:] = scale * (b < n_split ? g_a[b,:] : g_b[b - n_split,:]) (NULL part = 0),
+ * grad_grad[b, l*C+c] = sum_d gg_out[b,d] * dy_dx[l,b,d,c].
+ * msdf_hash_node_scatter: msdf_hash_encode_backward_fused_out with point-major grad_first / grad_second. */
+int msdf_hash_node_forward(const float* x, float divide_factor, float* x01_out, const float* embeddings,
+                           const int* offsets, float* feat, uint32_t pitch, uint32_t B, uint32_t C, uint32_t L,
+                           float S, uint32_t H, float* dy_dx, void* stream);
+int msdf_hash_node_input_gradient(const float* g, uint32_t pitch, const float* dy_dx, uint32_t B, uint32_t C,
+                                  uint32_t L, float scale, float* inout, void* stream);
+int msdf_hash_node_second_grad(const float* g_a, const float* g_b, uint32_t n_split, float scale, float* gg_out,
+                               const float* dy_dx, float* grad_grad, uint32_t pitch, uint32_t B, uint32_t C,
+                               uint32_t L, void* stream);
+int msdf_hash_transpose(const float* src, float* dst, const float* src2, float* dst2, uint32_t L, uint32_t B,
+                        uint32_t C, uint32_t pitch, int to_point_major, void* stream);
+int msdf_hash_node_scatter(const float* grad_first, const float* grad_second, uint32_t pitch, const float* inputs,
+                           const int* offsets, float* grad_embeddings, uint32_t B, uint32_t C, uint32_t L, float S,
+                           uint32_t H, const float* grad_grad_inputs, uint64_t n_entries, void* workspace,
+                           uint64_t workspace_bytes, void* stream);
 
 /* ---- fused MLPs ----
  * Every entry point that takes a plan runs on the matrix core named by plan->precision (monosdf_plan.h):

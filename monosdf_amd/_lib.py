@@ -150,6 +150,14 @@ _SIGNATURES = {
                                         C.c_float, C.c_uint32, _P, C.c_uint64, _P, C.c_uint64, _P],
     'msdf_hash_encode_backward_fused_out': [_P, _P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                             C.c_float, C.c_uint32, _P, C.c_uint64, _P, C.c_uint64, _P],
+    'msdf_hash_node_forward': [_P, C.c_float, _P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                               C.c_float, C.c_uint32, _P, _P],
+    'msdf_hash_node_input_gradient': [_P, C.c_uint32, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, _P, _P],
+    'msdf_hash_node_second_grad': [_P, _P, C.c_uint32, C.c_float, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32,
+                                   C.c_uint32, _P],
+    'msdf_hash_transpose': [_P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, _P],
+    'msdf_hash_node_scatter': [_P, _P, C.c_uint32, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float,
+                               C.c_uint32, _P, C.c_uint64, _P, C.c_uint64, _P],
     'msdf_weightnorm_forward': [_P, _P, C.c_int, _P, _P, _P, _P],
     'msdf_weightnorm_backward': [_P, _P, C.c_int, _P, _P, _P, _P, _P],
     'msdf_pack_weights': [C.POINTER(Plan), _P, _P, _P, _P, _P, _P, _P],
@@ -177,7 +185,7 @@ _SIGNATURES = {
     'msdf_laplace_density_backward': [_P, _P, C.c_int, C.c_int64, C.c_int, _P, _P, _P, _P],
 }
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _lib = None
 

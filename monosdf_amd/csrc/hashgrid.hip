@@ -81,9 +81,8 @@ __device__ __forceinline__ uint32_t hg_index_lv(const HgLevel& lv, const uint32_
   return (index < lv.hsize) ? index : index % lv.hsize;
 }
 
-__device__ __forceinline__ HgCell hg_locate(const float* __restrict__ inputs, const HgLevel& lv, const uint32_t b) {
+__device__ __forceinline__ HgCell hg_locate_xyz(const float x, const float y, const float z, const HgLevel& lv) {
   HgCell c;
-  const float x = inputs[(size_t)b * 3 + 0], y = inputs[(size_t)b * 3 + 1], z = inputs[(size_t)b * 3 + 2];
   c.oob = (x < 0.f || x > 1.f || y < 0.f || y > 1.f || z < 0.f || z > 1.f);
   c.hsize = lv.hsize;
   c.scale = lv.scale;
@@ -97,6 +96,10 @@ __device__ __forceinline__ HgCell hg_locate(const float* __restrict__ inputs, co
   return c;
 }
 
+__device__ __forceinline__ HgCell hg_locate(const float* __restrict__ inputs, const HgLevel& lv, const uint32_t b) {
+  return hg_locate_xyz(inputs[(size_t)b * 3 + 0], inputs[(size_t)b * 3 + 1], inputs[(size_t)b * 3 + 2], lv);
+}
+
 __device__ __forceinline__ HgCell hg_locate(const float* __restrict__ inputs, const int* __restrict__ offsets,
                                             const uint32_t b, const uint32_t level, const float S,
                                             const uint32_t H) {
@@ -108,17 +111,10 @@ __device__ __forceinline__ HgCell hg_locate(const float* __restrict__ inputs, co
 // ---------------------------------------------------------------------------
 // one (point, level): the 8 corner reads feed the output and its three directional derivatives
 template <int C>
-__device__ __forceinline__ void hg_forward_point(const float* __restrict__ inputs, const float* __restrict__ grid,
-                                                 const int* __restrict__ offsets, float* __restrict__ outputs,
-                                                 const uint32_t B, const uint32_t L, const HgLevel& lv,
-                                                 const uint32_t level, const uint32_t b, const int calc_grad_inputs,
-                                                 float* __restrict__ dy_dx) {
-  float* out = outputs + ((size_t)level * B + b) * C;
-  // calc_grad_inputs == 2: dy_dx level-major [L, B, 3 C] (a wave writes 64 x 3 C contiguous floats) instead of the
-  // reference's [B, L, 3 C] (3 C floats every L 3 C: partial lines written by 16 different launches' blocks)
-  float* dy = (calc_grad_inputs == 2) ? dy_dx + ((size_t)level * B + b) * 3 * C
-                                      : dy_dx + (size_t)b * 3 * L * C + (size_t)level * 3 * C;
-  const HgCell c = hg_locate(inputs, lv, b);
+__device__ __forceinline__ void hg_forward_cell(const HgCell& c, const float* __restrict__ grid,
+                                                const int* __restrict__ offsets, float* __restrict__ out,
+                                                const HgLevel& lv, const uint32_t level, const int calc_grad_inputs,
+                                                float* __restrict__ dy) {
   if (c.oob) {
 #pragma unroll
     for (int ch = 0; ch < C; ++ch) out[ch] = 0.f;
@@ -177,7 +173,98 @@ hg_forward_kernel(const float* __restrict__ inputs, const float* __restrict__ gr
   if (b >= B) return;
   const uint32_t level = blockIdx.y;
   const HgLevel lv = hg_level(offsets, level, S, H);
-  hg_forward_point<C>(inputs, grid, offsets, outputs, B, L, lv, level, b, calc_grad_inputs, dy_dx);
+  float* out = outputs + ((size_t)level * B + b) * C;
+  // calc_grad_inputs == 2: dy_dx level-major [L, B, 3 C] (a wave writes 64 x 3 C contiguous floats) instead of the
+  // reference's [B, L, 3 C] (3 C floats every L 3 C: partial lines written by 16 different launches' blocks)
+  float* dy = (calc_grad_inputs == 2) ? dy_dx + ((size_t)level * B + b) * 3 * C
+                                      : dy_dx + (size_t)b * 3 * L * C + (size_t)level * 3 * C;
+  hg_forward_cell<C>(hg_locate(inputs, lv, b), grid, offsets, out, lv, level, calc_grad_inputs, dy);
+}
+
+// ---------------------------------------------------------------------------
+// "Node" forms (ops.GridSdfFunction, the sampler's evaluations): the same arithmetic with the tensors laid out as
+// the fused MLP kernels read and write them, and the elementwise steps around the encoder done here instead of as
+// PyTorch launches:
+//   * points arrive in world coordinates; x01 = (x * inv_divide + 1) * 0.5 is formed per lane exactly as the
+//     module's tensor expression rounds it (a multiply by the fp32 reciprocal, an add, a multiply) and stored once;
+//   * features, d sdf / d features and their gradients: pitch == 0 keeps the kernels' own level-major [L, B, C] layout
+//     (coalesced: a wave touches 64 C contiguous floats); pitch > 0: point-major rows of `pitch` floats ([B, pitch],
+//     level l channel c at column l C + c, columns >= L C zeroed), the layout of the fused SDF kernels' input tiles.
+//     Point-major is free in the two small kernels (hg_node_input_gradient / hg_node_second_grad) and costly in the
+//     two large ones (8-byte pieces at a 128-byte stride: forward 0.115 -> 0.148 ms per step, the scatter 0.120 ->
+//     0.163), so ops.GridSdfFunction uses it for the former and msdf_hash_transpose (LDS tiles, both sides coalesced)
+//     around the latter -- instead of five strided tensor copies of 11-48 us per training step.
+// ---------------------------------------------------------------------------
+template <int C>
+__global__ void __launch_bounds__(HG_THREADS)
+hg_node_forward_kernel(const float* __restrict__ x, const float inv_divide, float* __restrict__ x01_out,
+                       const float* __restrict__ grid, const int* __restrict__ offsets, float* __restrict__ feat,
+                       const uint32_t pitch, const uint32_t B, const uint32_t L, const float S, const uint32_t H,
+                       float* __restrict__ dy_dx) {
+  const uint32_t b = blockIdx.x * HG_THREADS + threadIdx.x;
+  if (b >= B) return;
+  const uint32_t level = blockIdx.y;
+  const HgLevel lv = hg_level(offsets, level, S, H);
+  const float u0 = (x[(size_t)b * 3 + 0] * inv_divide + 1.0f) * 0.5f;
+  const float u1 = (x[(size_t)b * 3 + 1] * inv_divide + 1.0f) * 0.5f;
+  const float u2 = (x[(size_t)b * 3 + 2] * inv_divide + 1.0f) * 0.5f;
+  if (level == 0) {
+    if (x01_out != nullptr) {
+      x01_out[(size_t)b * 3 + 0] = u0; x01_out[(size_t)b * 3 + 1] = u1; x01_out[(size_t)b * 3 + 2] = u2;
+    }
+    for (uint32_t k = L * C; k < pitch; ++k) feat[(size_t)b * pitch + k] = 0.f;
+  }
+  float* dy = (dy_dx != nullptr) ? dy_dx + ((size_t)level * B + b) * 3 * C : nullptr;
+  float* out = pitch ? feat + (size_t)b * pitch + level * C : feat + ((size_t)level * B + b) * C;
+  hg_forward_cell<C>(hg_locate_xyz(u0, u1, u2, lv), grid, offsets, out, lv, level, dy != nullptr ? 2 : 0, dy);
+}
+
+// inout[b,d] += scale * sum_{l,c} g[b, l C + c] * dy_dx[l,b,d,c]   (the grid part of d sdf / d x, chain rule factor in)
+template <int C>
+__global__ void __launch_bounds__(HG_THREADS)
+hg_node_input_gradient_kernel(const float* __restrict__ g, const uint32_t pitch, const float* __restrict__ dy_dx,
+                              const uint32_t B, const uint32_t L, const float scale, float* __restrict__ inout) {
+  const uint32_t b = blockIdx.x * HG_THREADS + threadIdx.x;
+  if (b >= B) return;
+  float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+  for (uint32_t l = 0; l < L; ++l) {
+    const float* dy = dy_dx + ((size_t)l * B + b) * 3 * C;
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) {
+      const float gv = pitch ? g[(size_t)b * pitch + l * C + ch] : g[((size_t)l * B + b) * C + ch];
+      r0 += gv * dy[0 * C + ch];
+      r1 += gv * dy[1 * C + ch];
+      r2 += gv * dy[2 * C + ch];
+    }
+  }
+  const float t0 = r0 * scale, t1 = r1 * scale, t2 = r2 * scale;       // rounded products, then the sums (as the tensor
+  inout[(size_t)b * 3 + 0] += t0;                                       // expression nrm + through * k rounds them)
+  inout[(size_t)b * 3 + 1] += t1;
+  inout[(size_t)b * 3 + 2] += t2;
+}
+
+// gg[b] = scale * (b < n_split ? g_a[b] : g_b[b - n_split])  (a missing part is zero), stored once;
+// grad_grad[b, l C + c] = sum_d gg[b,d] * dy_dx[l,b,d,c]
+template <int C>
+__global__ void __launch_bounds__(HG_THREADS)
+hg_node_second_grad_kernel(const float* __restrict__ g_a, const float* __restrict__ g_b, const uint32_t n_split,
+                           const float scale, float* __restrict__ gg_out, const float* __restrict__ dy_dx,
+                           float* __restrict__ grad_grad, const uint32_t pitch, const uint32_t B, const uint32_t L) {
+  const uint32_t b = blockIdx.x * HG_THREADS + threadIdx.x;
+  if (b >= B) return;
+  const uint32_t level = blockIdx.y;
+  const float* src = (b < n_split) ? g_a : g_b;
+  const size_t j = (b < n_split) ? b : b - n_split;
+  float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+  if (src != nullptr) { g0 = src[j * 3 + 0] * scale; g1 = src[j * 3 + 1] * scale; g2 = src[j * 3 + 2] * scale; }
+  if (level == 0) {
+    gg_out[(size_t)b * 3 + 0] = g0; gg_out[(size_t)b * 3 + 1] = g1; gg_out[(size_t)b * 3 + 2] = g2;
+    for (uint32_t k = L * C; k < pitch; ++k) grad_grad[(size_t)b * pitch + k] = 0.f;
+  }
+  const float* dy = dy_dx + ((size_t)level * B + b) * 3 * C;
+  float* out = pitch ? grad_grad + (size_t)b * pitch + level * C : grad_grad + ((size_t)level * B + b) * C;
+#pragma unroll
+  for (int ch = 0; ch < C; ++ch) out[ch] = g0 * dy[0 * C + ch] + g1 * dy[1 * C + ch] + g2 * dy[2 * C + ch];
 }
 
 // ---------------------------------------------------------------------------
@@ -733,7 +820,8 @@ template <int C, int MODE>
 __global__ void __launch_bounds__(HB_THREADS)
 hb2_place_k(const float* __restrict__ grad, const float* __restrict__ grad2, const float* __restrict__ inputs,
             const int* __restrict__ offsets, const float* __restrict__ gg_inputs, int* __restrict__ ws,
-            const Hb2Layout y, const uint32_t B, const float S, const uint32_t H, float* __restrict__ zero_grid) {
+            const Hb2Layout y, const uint32_t B, const float S, const uint32_t H, float* __restrict__ zero_grid,
+            const uint32_t pitch) {       // pitch > 0: grad / grad2 are point-major [B, pitch] (level l, channel c at l C + c)
   extern __shared__ int hb2_lds[];
   int* hist = hb2_lds;                       // [ns]: counts, then run starts
   int* part = hb2_lds + y.ns_bound + 1;      // [HB_THREADS] scan scratch
@@ -835,8 +923,9 @@ hb2_place_k(const float* __restrict__ grad, const float* __restrict__ grad2, con
     float g1[C], g2[C];
 #pragma unroll
     for (int ch = 0; ch < C; ++ch) {
-      g1[ch] = live ? grad[((size_t)level * B + bc) * C + ch] : 0.f;
-      g2[ch] = (MODE == 2 && live) ? grad2[((size_t)level * B + bc) * C + ch] : 0.f;
+      const size_t gi = pitch ? (size_t)bc * pitch + level * C + ch : ((size_t)level * B + bc) * C + ch;
+      g1[ch] = live ? grad[gi] : 0.f;
+      g2[ch] = (MODE == 2 && live) ? grad2[gi] : 0.f;
     }
     const bool head = (heads >> p) & 1u;
 #pragma unroll
@@ -999,7 +1088,7 @@ template <int C, int MODE>
 static int hb_run(const float* grad, const float* grad2, const float* inputs, const int* offsets,
                   const float* gg_inputs, float* grad_grid, const uint32_t B, const uint32_t L, const float S,
                   const uint32_t H, const uint64_t n_entries, void* workspace, const size_t workspace_bytes,
-                  hipStream_t st, const bool overwrite = false) {
+                  hipStream_t st, const bool overwrite = false, const uint32_t pitch = 0) {
   if (n_entries * C >= (1ull << 31) || (uint64_t)B * L * 8 >= (1ull << 31)) return MSDF_ERR_UNSUPPORTED;
   int* ws = (int*)workspace;
   const Hb2Layout y2 = hb2_layout(B, C, L, n_entries);
@@ -1007,10 +1096,11 @@ static int hb_run(const float* grad, const float* grad2, const float* inputs, co
     if (workspace == nullptr || workspace_bytes < y2.total_bytes || ((uintptr_t)workspace & 15)) return MSDF_ERR_ARG;
     const size_t lds = (size_t)(y2.ns_bound + 1 + HB_THREADS) * sizeof(int);
     hb2_place_k<C, MODE><<<dim3((unsigned)y2.n_wg, L), HB_THREADS, lds, st>>>(grad, grad2, inputs, offsets, gg_inputs, ws,
-                                                                             y2, B, S, H, overwrite ? grad_grid : nullptr);
+                                                                             y2, B, S, H, overwrite ? grad_grid : nullptr, pitch);
     hb2_accumulate_k<C><<<(unsigned)y2.work_max, HB_THREADS, 0, st>>>(ws, y2, offsets, L, grad_grid, overwrite ? 1 : 0);
     return MSDF_OK;
   }
+  if (pitch != 0) return MSDF_ERR_UNSUPPORTED;      // the first form reads level-major gradients only
   if (overwrite && hipMemsetAsync(grad_grid, 0, (size_t)n_entries * C * sizeof(float), st) != hipSuccess) return MSDF_ERR_LAUNCH;
   const HbLayout y = hb_layout(B, C, L, n_entries);
   if (workspace == nullptr || workspace_bytes < y.total_bytes || ((uintptr_t)workspace & 15)) return MSDF_ERR_ARG;
@@ -1200,6 +1290,112 @@ extern "C" int msdf_hash_encode_backward_fused_out(const float* grad_first, cons
   HG_DISPATCH_C(C, {
     const int rc = hb_run<CC, 2>(grad_first, grad_second, inputs, offsets, grad_grad_inputs, grad_embeddings, B, L, S,
                                  H, n_entries, workspace, workspace_bytes, st, true);
+    if (rc != MSDF_OK) return rc;
+  });
+  return msdf_check_launch();
+}
+
+// [L, B, C] <-> [B, pitch] (level l, channel c of a point at column l C + c; columns >= L C zero) through an LDS tile
+// of 64 points: both the level-major side (64 C contiguous floats per level) and the point-major side (whole rows)
+// move as contiguous runs.  Up to two tensors of the same shape per launch.
+#define HT_PTS 64
+template <bool TO_PM>
+__global__ void __launch_bounds__(256)
+hg_transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, const float* __restrict__ src2,
+                    float* __restrict__ dst2, const uint32_t L, const uint32_t B, const uint32_t C,
+                    const uint32_t pitch) {
+  extern __shared__ float ht_tile[];                 // [HT_PTS][LC + 1]
+  const uint32_t LC = L * C, ld = LC + 1;
+  const uint32_t b0 = blockIdx.x * HT_PTS;
+  const float* in = blockIdx.y ? src2 : src;
+  float* out = blockIdx.y ? dst2 : dst;
+  const uint32_t n_pts = min((uint32_t)HT_PTS, B - b0);
+  if (TO_PM) {
+    for (uint32_t i = threadIdx.x; i < L * n_pts * C; i += 256) {          // level-major reads: runs of n_pts * C floats
+      const uint32_t l = i / (n_pts * C), r = i - l * (n_pts * C);
+      ht_tile[(r / C) * ld + l * C + (r % C)] = in[((size_t)l * B + b0) * C + r];
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_pts * pitch; i += 256) {          // rows out
+      const uint32_t p = i / pitch, k = i - p * pitch;
+      out[(size_t)(b0 + p) * pitch + k] = (k < LC) ? ht_tile[p * ld + k] : 0.f;
+    }
+  } else {
+    for (uint32_t i = threadIdx.x; i < n_pts * LC; i += 256) {             // rows in
+      const uint32_t p = i / LC, k = i - p * LC;
+      ht_tile[p * ld + k] = in[(size_t)(b0 + p) * pitch + k];
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < L * n_pts * C; i += 256) {
+      const uint32_t l = i / (n_pts * C), r = i - l * (n_pts * C);
+      out[((size_t)l * B + b0) * C + r] = ht_tile[(r / C) * ld + l * C + (r % C)];
+    }
+  }
+}
+
+extern "C" int msdf_hash_transpose(const float* src, float* dst, const float* src2, float* dst2, uint32_t L,
+                                   uint32_t B, uint32_t C, uint32_t pitch, int to_point_major, void* stream) {
+  if (src == nullptr || dst == nullptr || (src2 == nullptr) != (dst2 == nullptr) || pitch < L * C || L * C == 0)
+    return MSDF_ERR_ARG;
+  if (B == 0) return MSDF_OK;
+  const size_t lds = (size_t)HT_PTS * (L * C + 1) * sizeof(float);
+  if (lds > 64 * 1024) return MSDF_ERR_UNSUPPORTED;
+  const dim3 grid((B + HT_PTS - 1) / HT_PTS, src2 != nullptr ? 2 : 1);
+  if (to_point_major) hg_transpose_kernel<true><<<grid, 256, lds, (hipStream_t)stream>>>(src, dst, src2, dst2, L, B, C, pitch);
+  else hg_transpose_kernel<false><<<grid, 256, lds, (hipStream_t)stream>>>(src, dst, src2, dst2, L, B, C, pitch);
+  return msdf_check_launch();
+}
+
+// ---- node forms (see hg_node_forward_kernel) ----
+extern "C" int msdf_hash_node_forward(const float* x, float divide_factor, float* x01_out, const float* embeddings,
+                                      const int* offsets, float* feat, uint32_t pitch, uint32_t B, uint32_t C,
+                                      uint32_t L, float S, uint32_t H, float* dy_dx, void* stream) {
+  if ((pitch != 0 && pitch < L * C) || x == nullptr || feat == nullptr) return MSDF_ERR_ARG;
+  if (B == 0) return MSDF_OK;
+  const float inv = 1.0f / divide_factor;        // fp32 reciprocal: what the module's `x / divide_factor` multiplies by
+  const dim3 grid((B + HG_THREADS - 1) / HG_THREADS, L);
+  HG_DISPATCH_C(C, (hg_node_forward_kernel<CC><<<grid, HG_THREADS, 0, (hipStream_t)stream>>>(
+                       x, inv, x01_out, embeddings, offsets, feat, pitch, B, L, S, H, dy_dx)));
+  return msdf_check_launch();
+}
+
+extern "C" int msdf_hash_node_input_gradient(const float* g, uint32_t pitch, const float* dy_dx, uint32_t B,
+                                             uint32_t C, uint32_t L, float scale, float* inout, void* stream) {
+  if ((pitch != 0 && pitch < L * C) || g == nullptr || dy_dx == nullptr || inout == nullptr) return MSDF_ERR_ARG;
+  if (B == 0) return MSDF_OK;
+  HG_DISPATCH_C(C, (hg_node_input_gradient_kernel<CC><<<(B + HG_THREADS - 1) / HG_THREADS, HG_THREADS, 0,
+                                                        (hipStream_t)stream>>>(g, pitch, dy_dx, B, L, scale, inout)));
+  return msdf_check_launch();
+}
+
+extern "C" int msdf_hash_node_second_grad(const float* g_a, const float* g_b, uint32_t n_split, float scale,
+                                          float* gg_out, const float* dy_dx, float* grad_grad, uint32_t pitch,
+                                          uint32_t B, uint32_t C, uint32_t L, void* stream) {
+  if ((pitch != 0 && pitch < L * C) || gg_out == nullptr || dy_dx == nullptr || grad_grad == nullptr || n_split > B)
+    return MSDF_ERR_ARG;
+  if (B == 0) return MSDF_OK;
+  const dim3 grid((B + HG_THREADS - 1) / HG_THREADS, L);
+  HG_DISPATCH_C(C, (hg_node_second_grad_kernel<CC><<<grid, HG_THREADS, 0, (hipStream_t)stream>>>(
+                       g_a, g_b, n_split, scale, gg_out, dy_dx, grad_grad, pitch, B, L)));
+  return msdf_check_launch();
+}
+
+// msdf_hash_encode_backward_fused_out with grad_first / grad_second as point-major rows of `pitch` floats
+extern "C" int msdf_hash_node_scatter(const float* grad_first, const float* grad_second, uint32_t pitch,
+                                      const float* inputs, const int* offsets, float* grad_embeddings, uint32_t B,
+                                      uint32_t C, uint32_t L, float S, uint32_t H, const float* grad_grad_inputs,
+                                      uint64_t n_entries, void* workspace, uint64_t workspace_bytes, void* stream) {
+  if (C == 1) return MSDF_ERR_UNSUPPORTED;
+  if ((pitch != 0 && pitch < L * C) || grad_embeddings == nullptr || grad_first == nullptr || grad_second == nullptr ||
+      grad_grad_inputs == nullptr)
+    return MSDF_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0)
+    return hipMemsetAsync(grad_embeddings, 0, (size_t)n_entries * C * sizeof(float), st) == hipSuccess ? MSDF_OK
+                                                                                                      : MSDF_ERR_LAUNCH;
+  HG_DISPATCH_C(C, {
+    const int rc = hb_run<CC, 2>(grad_first, grad_second, inputs, offsets, grad_grad_inputs, grad_embeddings, B, L, S,
+                                 H, n_entries, workspace, workspace_bytes, st, true, pitch);
     if (rc != MSDF_OK) return rc;
   });
   return msdf_check_launch();

@@ -409,82 +409,77 @@ class GridSdfFunction(torch.autograd.Function):
         B, D = x.shape
         L, Cdim, S, H = enc
         offsets = mlp.grid_offsets
-        x01 = ((x / divide_factor + 1.0) / 2.0).contiguous()
+        A = 16 * mlp.plan.aux_tiles                 # row pitch of the grid features as the SDF kernels read them
+        # the node forms of the hash kernels (csrc/hashgrid.hip): x01 formed inside the encoder kernel, which writes its
+        # own level-major [L, B, C] output; one LDS-tiled transpose turns it into the rows the SDF kernels read
+        x01 = torch.empty(B, D, device=x.device, dtype=torch.float32)
         outputs = torch.empty(L, B, Cdim, device=x.device, dtype=torch.float32)
+        aux = torch.empty(B, A, device=x.device, dtype=torch.float32)
         dy_dx = torch.empty(B, L * D * Cdim, device=x.device, dtype=torch.float32)
         st = _lib.stream_ptr()
-        _lib.call('msdf_hash_encode_forward', _lib.ptr(x01), _lib.ptr(emb), _lib.ptr(offsets), _lib.ptr(outputs), B, D,
-                  Cdim, L, S, H, 2, _lib.ptr(dy_dx), st)
-        A = 16 * mlp.plan.aux_tiles
-        aux = outputs.permute(1, 0, 2).reshape(B, L * Cdim)
-        if A != L * Cdim:
-            aux = torch.nn.functional.pad(aux, (0, A - L * Cdim))
+        _lib.call('msdf_hash_node_forward', _lib.ptr(x), float(divide_factor), _lib.ptr(x01), _lib.ptr(emb),
+                  _lib.ptr(offsets), _lib.ptr(outputs), 0, B, Cdim, L, S, H, _lib.ptr(dy_dx), st)
+        _lib.call('msdf_hash_transpose', _lib.ptr(outputs), _lib.ptr(aux), None, None, L, B, Cdim, A, 1, st)
         inner = _InnerCtx()
         # the grid class never clamps (network.py:290-309): clamp radius 0
         sdf_a, sdf_b, feat, nrm_a, nrm_b, r_aux = SdfMlpFunction.forward(
-            inner, x, aux.contiguous(), flat_w, flat_b, wpack, bpack, mlp, n_clamp, n_feat, 0.0, sphere_scale, save,
-            n_split)
-        # d sdf / d x through the grid: sum_{l,c} (d sdf / d feature) * d feature / d x01, chain rule to x
-        r_lbc = r_aux[:, :L * Cdim].reshape(B, L, Cdim).permute(1, 0, 2).contiguous()
-        through = torch.empty(B, D, device=x.device, dtype=torch.float32)
-        _lib.call('msdf_hash_encode_backward', _lib.ptr(r_lbc), _lib.ptr(x01), _lib.ptr(emb), _lib.ptr(offsets), None,
-                  B, D, Cdim, L, S, H, 2, _lib.ptr(dy_dx), _lib.ptr(through), st)
+            inner, x, aux, flat_w, flat_b, wpack, bpack, mlp, n_clamp, n_feat, 0.0, sphere_scale, save, n_split)
+        # d sdf / d x through the grid: sum_{l,c} (d sdf / d feature) * d feature / d x01, chain rule to x, added to the
+        # MLP's own d sdf / d x in place (nrm_a / nrm_b are the two halves of ONE [B,3] buffer starting at nrm_a)
         k = 0.5 / divide_factor
-        ns = inner.n_split
-        through = through * k
-        nrm_a = nrm_a + through[:ns]
-        nrm_b = nrm_b + through[ns:]
+        assert nrm_a.data_ptr() + 12 * nrm_a.shape[0] == nrm_b.data_ptr() or nrm_b.shape[0] == 0
+        _lib.call('msdf_hash_node_input_gradient', _lib.ptr(r_aux), A, _lib.ptr(dy_dx), B, Cdim, L, float(k),
+                  _lib.ptr(nrm_a), st)
         ctx.inner, ctx.enc, ctx.k, ctx.n_entries = inner, enc, k, emb.shape[0]
         ctx.offsets = offsets
-        ctx.save_for_backward(x01, dy_dx, r_lbc, *inner.saved_tensors)
+        ctx.save_for_backward(x01, dy_dx, r_aux, *inner.saved_tensors)
         inner.saved_tensors = ()
         return sdf_a, sdf_b, feat, nrm_a, nrm_b
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_sdf, g_sdf_b, g_feat, g_nrm, g_nrm_b):
-        x01, dy_dx, r_lbc, *inner_saved = ctx.saved_tensors
+        x01, dy_dx, r_aux, *inner_saved = ctx.saved_tensors
         inner, (L, Cdim, S, H), k = ctx.inner, ctx.enc, ctx.k
         inner.saved_tensors = tuple(inner_saved)
         B, D = x01.shape
         dev = x01.device
         ns = inner.n_split
         st = _lib.stream_ptr()
-        # gradient arriving at the grid part of d sdf/dx (the reference's grad_grad_inputs, hashgrid.py:71-84)
-        gg = torch.zeros(B, D, device=dev, dtype=torch.float32)
-        if g_nrm is not None:
-            gg[:ns] = g_nrm
-        if g_nrm_b is not None:
-            gg[ns:] = g_nrm_b
-        gg.mul_(k)
-        # ... its term for d sdf / d feature: grad_grad[l,b,c] = sum_d gg[b,d] dy_dx[b,l,d,c]
-        grad_grad = torch.empty(L, B, Cdim, device=dev, dtype=torch.float32)
-        _lib.call('msdf_hash_encode_second_backward_ws', _lib.ptr(r_lbc), _lib.ptr(x01), None, _lib.ptr(ctx.offsets), B, D,
-                  Cdim, L, S, H, 2, _lib.ptr(dy_dx), _lib.ptr(gg), _lib.ptr(grad_grad), None, ctx.n_entries, None, 0, st)
         A = 16 * inner.mlp.plan.aux_tiles
-        g_raux = grad_grad.permute(1, 0, 2).reshape(B, L * Cdim)
-        if A != L * Cdim:
-            g_raux = torch.nn.functional.pad(g_raux, (0, A - L * Cdim))
+        # gradient arriving at the grid part of d sdf/dx (the reference's grad_grad_inputs, hashgrid.py:71-84), scaled
+        # by the chain-rule factor, and its term for d sdf / d feature: grad_grad[b, l C + c] = sum_d gg[b,d] dy_dx --
+        # one launch, written as the rows the SDF backward kernel reads
+        gg = torch.empty(B, D, device=dev, dtype=torch.float32)
+        g_raux = torch.empty(B, A, device=dev, dtype=torch.float32)
+        cont = lambda t: None if t is None else t.contiguous()
+        g_nrm_c, g_nrm_b_c = cont(g_nrm), cont(g_nrm_b)
+        _lib.call('msdf_hash_node_second_grad', _lib.ptr(g_nrm_c) if g_nrm_c is not None else None,
+                  _lib.ptr(g_nrm_b_c) if g_nrm_b_c is not None else None, ns, float(k), _lib.ptr(gg), _lib.ptr(dy_dx),
+                  _lib.ptr(g_raux), A, B, Cdim, L, st)
         done = []
 
         def scatter(g_aux):
             """Both embedding gradients in ONE binned scatter, launched between the MLP's sweeps and its weight-gradient
             kernels: the 48.8 MB result is then complete ~2 ms before the node's backward ends, and a multi-GPU run
             exchanges it under the weight-gradient kernels (parallel.GradientAverager)."""
-            g1 = g_aux[:, :L * Cdim].reshape(B, L, Cdim).permute(1, 0, 2).contiguous()
             # the "=" form: the table gradient is written, not added to -- no 48.8 MB zero fill, no read of the table
             g_emb = torch.empty(ctx.n_entries, Cdim, device=dev, dtype=torch.float32)
             nbytes = _lib.load().msdf_hash_scatter_workspace_bytes(B, Cdim, L, ctx.n_entries)
             ws = torch.empty(int(nbytes), device=dev, dtype=torch.uint8)
-            _lib.call('msdf_hash_encode_backward_fused_out', _lib.ptr(g1), _lib.ptr(r_lbc), _lib.ptr(x01),
-                      _lib.ptr(ctx.offsets), _lib.ptr(g_emb), B, D, Cdim, L, S, H, _lib.ptr(gg), ctx.n_entries,
+            # the scatter reads level-major gradients (coalesced): both operands transposed in ONE launch
+            g_lm = torch.empty(2, L, B, Cdim, device=dev, dtype=torch.float32)
+            _lib.call('msdf_hash_transpose', _lib.ptr(g_aux), _lib.ptr(g_lm[0]), _lib.ptr(r_aux), _lib.ptr(g_lm[1]), L, B,
+                      Cdim, A, 0, st)
+            _lib.call('msdf_hash_node_scatter', _lib.ptr(g_lm[0]), _lib.ptr(g_lm[1]), 0, _lib.ptr(x01),
+                      _lib.ptr(ctx.offsets), _lib.ptr(g_emb), B, Cdim, L, S, H, _lib.ptr(gg), ctx.n_entries,
                       _lib.ptr(ws), int(nbytes), st)
             parallel.mark_grad_ready(g_emb)
             done.append(g_emb)
 
         inner.after_sweeps = scatter
         try:
-            res = SdfMlpFunction.backward(inner, g_sdf, g_sdf_b, g_feat, g_nrm, g_nrm_b, g_raux.contiguous())
+            res = SdfMlpFunction.backward(inner, g_sdf, g_sdf_b, g_feat, g_nrm, g_nrm_b, g_raux)
         finally:
             inner.after_sweeps = None
             inner.saved_tensors = ()
@@ -492,6 +487,22 @@ class GridSdfFunction(torch.autograd.Function):
         # the only reference to the table gradient leaves with the return value: autograd then adopts the tensor as
         # embeddings.grad instead of copying 48.8 MB
         return (None, done.pop(), g_w, g_b) + (None,) * 10
+
+
+def hash_node_features(x, divide_factor, embeddings, offsets, enc, pitch):
+    """Grid features of the points x (world coordinates) as rows of `pitch` floats, no gradient: what the sampler's SDF
+    evaluations feed the fused forward kernel -- x01 inside the encoder kernel, then one LDS-tiled transpose."""
+    x = _need_cuda(x.detach(), 'points')
+    emb = _need_cuda(embeddings.detach(), 'embeddings')
+    L, Cdim, S, H = enc
+    B = x.shape[0]
+    st = _lib.stream_ptr()
+    outputs = torch.empty(L, B, Cdim, device=x.device, dtype=torch.float32)
+    aux = torch.empty(B, pitch, device=x.device, dtype=torch.float32)
+    _lib.call('msdf_hash_node_forward', _lib.ptr(x), float(divide_factor), None, _lib.ptr(emb), _lib.ptr(offsets),
+              _lib.ptr(outputs), 0, B, Cdim, L, S, H, None, st)
+    _lib.call('msdf_hash_transpose', _lib.ptr(outputs), _lib.ptr(aux), None, None, L, B, Cdim, pitch, 1, st)
+    return aux
 
 
 # ---------------------------------------------------------------------------

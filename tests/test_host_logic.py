@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in _declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.msdf_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.msdf_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_struct_sizes_match_header():
