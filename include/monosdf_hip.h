@@ -110,7 +110,7 @@ int msdf_hash_encode_backward_fused_out(const float* grad_first, const float* gr
  * msdf_hash_node_second_grad: gg_out[b,:] = scale * (b < n_split ? g_a[b,:] : g_b[b - n_split,:]) (NULL part = 0),
  * grad_grad[b, l*C+c] = sum_d gg_out[b,d] * dy_dx[l,b,d,c].
  * msdf_hash_node_scatter: msdf_hash_encode_backward_fused_out with point-major grad_first / grad_second. */
-int msdf_hash_node_forward(const float* x, float divide_factor, float* x01_out, const float* embeddings,
+int msdf_hash_node_forward(const float* x, double divide_factor, float* x01_out, const float* embeddings,
                            const int* offsets, float* feat, uint32_t pitch, uint32_t B, uint32_t C, uint32_t L,
                            float S, uint32_t H, float* dy_dx, void* stream);
 int msdf_hash_node_input_gradient(const float* g, uint32_t pitch, const float* dy_dx, uint32_t B, uint32_t C,

@@ -150,7 +150,7 @@ _SIGNATURES = {
                                         C.c_float, C.c_uint32, _P, C.c_uint64, _P, C.c_uint64, _P],
     'msdf_hash_encode_backward_fused_out': [_P, _P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                             C.c_float, C.c_uint32, _P, C.c_uint64, _P, C.c_uint64, _P],
-    'msdf_hash_node_forward': [_P, C.c_float, _P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+    'msdf_hash_node_forward': [_P, C.c_double, _P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                C.c_float, C.c_uint32, _P, _P],
     'msdf_hash_node_input_gradient': [_P, C.c_uint32, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, _P, _P],
     'msdf_hash_node_second_grad': [_P, _P, C.c_uint32, C.c_float, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32,

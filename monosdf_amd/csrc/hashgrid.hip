@@ -186,7 +186,8 @@ hg_forward_kernel(const float* __restrict__ inputs, const float* __restrict__ gr
 // the fused MLP kernels read and write them, and the elementwise steps around the encoder done here instead of as
 // PyTorch launches:
 //   * points arrive in world coordinates; x01 = (x * inv_divide + 1) * 0.5 is formed per lane exactly as the
-//     module's tensor expression rounds it (a multiply by the fp32 reciprocal, an add, a multiply) and stored once;
+//     module's tensor expression rounds it (a multiply by the reciprocal -- formed in double, rounded to fp32 --
+//     an add, a multiply) and stored once;
 //   * features, d sdf / d features and their gradients: pitch == 0 keeps the kernels' own level-major [L, B, C] layout
 //     (coalesced: a wave touches 64 C contiguous floats); pitch > 0: point-major rows of `pitch` floats ([B, pitch],
 //     level l channel c at column l C + c, columns >= L C zeroed), the layout of the fused SDF kernels' input tiles.
@@ -1347,12 +1348,14 @@ extern "C" int msdf_hash_transpose(const float* src, float* dst, const float* sr
 }
 
 // ---- node forms (see hg_node_forward_kernel) ----
-extern "C" int msdf_hash_node_forward(const float* x, float divide_factor, float* x01_out, const float* embeddings,
+extern "C" int msdf_hash_node_forward(const float* x, double divide_factor, float* x01_out, const float* embeddings,
                                       const int* offsets, float* feat, uint32_t pitch, uint32_t B, uint32_t C,
                                       uint32_t L, float S, uint32_t H, float* dy_dx, void* stream) {
   if ((pitch != 0 && pitch < L * C) || x == nullptr || feat == nullptr) return MSDF_ERR_ARG;
   if (B == 0) return MSDF_OK;
-  const float inv = 1.0f / divide_factor;        // fp32 reciprocal: what the module's `x / divide_factor` multiplies by
+  // what the module's `x / divide_factor` multiplies by on the device: the reciprocal formed in double, rounded to
+  // fp32 (scripts/dbg/x01_rounding.py: bit-identical on 196,608 values; 1.0f / 1.1f differs in 41 % of them)
+  const float inv = (float)(1.0 / divide_factor);
   const dim3 grid((B + HG_THREADS - 1) / HG_THREADS, L);
   HG_DISPATCH_C(C, (hg_node_forward_kernel<CC><<<grid, HG_THREADS, 0, (hipStream_t)stream>>>(
                        x, inv, x01_out, embeddings, offsets, feat, pitch, B, L, S, H, dy_dx)));

@@ -283,6 +283,83 @@ def test_hash_encoder_kernels():
                       _lib.ptr(ws), nbytes - 1, st)
 
 
+def test_hash_node_forms_equal_the_reference_order_kernels():
+    """The node forms (msdf_hash_node_*) are the reference-order kernels with the elementwise steps around them folded
+    in and another tensor layout: through raw ctypes, bit for bit against the reference-order entry points fed with the
+    tensor expressions the module would run (x01, the chain-rule factor, the scaled grad_grad_inputs), both layouts;
+    msdf_hash_transpose round trip."""
+    from oracle import hashgrid_oracle as hg
+    from monosdf_amd import _lib
+    g = torch.Generator().manual_seed(29)
+    for ic in [dict(num_levels=16, level_dim=2, logmap=19, base_size=16, end_size=2048),
+               dict(num_levels=3, level_dim=8, logmap=11, base_size=4, end_size=32),
+               dict(num_levels=6, level_dim=4, logmap=12, base_size=8, end_size=128)]:
+        geo = hg.level_geometry(ic)
+        B, L, C = 777, geo['L'], geo['C']
+        pitch = ((L * C + 15) // 16) * 16
+        df = 1.1
+        xw = ((torch.rand(B, 3, generator=g) * 2 - 1) * 1.15).cuda()       # some points leave the cube
+        emb = (torch.rand(geo['n_entries'], C, generator=g) - 0.5).cuda()
+        offs = torch.tensor(geo['offsets'], dtype=torch.int32).cuda()
+        st = _lib.stream_ptr()
+        x01 = ((xw / df + 1.0) / 2.0).contiguous()                         # the module's expression, on the device
+        out = torch.empty(L, B, C, device='cuda')
+        dy = torch.empty(L, B, 3 * C, device='cuda')
+        _lib.call('msdf_hash_encode_forward', _lib.ptr(x01), _lib.ptr(emb), _lib.ptr(offs), _lib.ptr(out), B, 3, C, L,
+                  geo['S'], geo['H'], 2, _lib.ptr(dy), st)
+        for p_ in (0, pitch):
+            x01_n = torch.empty(B, 3, device='cuda')
+            feat = torch.full((L, B, C) if p_ == 0 else (B, p_), float('nan'), device='cuda')
+            dy_n = torch.empty(L, B, 3 * C, device='cuda')
+            _lib.call('msdf_hash_node_forward', _lib.ptr(xw), df, _lib.ptr(x01_n), _lib.ptr(emb), _lib.ptr(offs),
+                      _lib.ptr(feat), p_, B, C, L, geo['S'], geo['H'], _lib.ptr(dy_n), st)
+            assert torch.equal(x01_n, x01) and torch.equal(dy_n, dy)
+            want = out if p_ == 0 else torch.nn.functional.pad(out.permute(1, 0, 2).reshape(B, L * C), (0, p_ - L * C))
+            assert torch.equal(feat, want)
+        # transposes: [L,B,C] -> rows -> [L,B,C], one and two tensors per launch
+        rows = torch.full((B, pitch), float('nan'), device='cuda')
+        _lib.call('msdf_hash_transpose', _lib.ptr(out), _lib.ptr(rows), None, None, L, B, C, pitch, 1, st)
+        assert torch.equal(rows, torch.nn.functional.pad(out.permute(1, 0, 2).reshape(B, L * C), (0, pitch - L * C)))
+        back = torch.empty(2, L, B, C, device='cuda')
+        rows2 = (rows * 2).contiguous()
+        _lib.call('msdf_hash_transpose', _lib.ptr(rows), _lib.ptr(back[0]), _lib.ptr(rows2), _lib.ptr(back[1]), L, B, C,
+                  pitch, 0, st)
+        assert torch.equal(back[0], out) and torch.equal(back[1], out * 2)
+        # input gradient: nrm + (sum g dy) * k, as the tensor expression rounds it
+        k = 0.5 / df
+        g_rows = torch.randn(B, pitch, generator=g).cuda()
+        g_lm = g_rows[:, :L * C].reshape(B, L, C).permute(1, 0, 2).contiguous()
+        through = torch.empty(B, 3, device='cuda')
+        _lib.call('msdf_hash_encode_backward', _lib.ptr(g_lm), _lib.ptr(x01), _lib.ptr(emb), _lib.ptr(offs), None, B, 3,
+                  C, L, geo['S'], geo['H'], 2, _lib.ptr(dy), _lib.ptr(through), st)
+        nrm = torch.randn(B, 3, generator=g).cuda()
+        want = nrm + through * k
+        for p_, gp in ((pitch, g_rows), (0, g_lm)):
+            got = nrm.clone()
+            _lib.call('msdf_hash_node_input_gradient', _lib.ptr(gp), p_, _lib.ptr(dy), B, C, L, float(k), _lib.ptr(got), st)
+            assert torch.equal(got, want)
+        # second-order term: gg = [g_a; g_b] * k, grad_grad = sum_d gg dy
+        ns = 500
+        g_a, g_b = torch.randn(ns, 3, generator=g).cuda(), torch.randn(B - ns, 3, generator=g).cuda()
+        gg = torch.cat([g_a, g_b]) * k
+        ggrad = torch.empty(L, B, C, device='cuda')
+        _lib.call('msdf_hash_encode_second_backward_ws', _lib.ptr(g_lm), _lib.ptr(x01), None, _lib.ptr(offs), B, 3, C, L,
+                  geo['S'], geo['H'], 2, _lib.ptr(dy), _lib.ptr(gg), _lib.ptr(ggrad), None, geo['n_entries'], None, 0, st)
+        for p_ in (0, pitch):
+            gg_n = torch.empty(B, 3, device='cuda')
+            gr_n = torch.full((L, B, C) if p_ == 0 else (B, p_), float('nan'), device='cuda')
+            _lib.call('msdf_hash_node_second_grad', _lib.ptr(g_a), _lib.ptr(g_b), ns, float(k), _lib.ptr(gg_n), _lib.ptr(dy),
+                      _lib.ptr(gr_n), p_, B, C, L, st)
+            want = ggrad if p_ == 0 else torch.nn.functional.pad(ggrad.permute(1, 0, 2).reshape(B, L * C), (0, p_ - L * C))
+            assert torch.equal(gg_n, gg) and torch.equal(gr_n, want)
+        # a missing half is zeros
+        gg_n = torch.empty(B, 3, device='cuda')
+        gr_n = torch.empty(L, B, C, device='cuda')
+        _lib.call('msdf_hash_node_second_grad', _lib.ptr(g_a), None, ns, float(k), _lib.ptr(gg_n), _lib.ptr(dy),
+                  _lib.ptr(gr_n), 0, B, C, L, st)
+        assert torch.equal(gg_n[:ns], g_a * k) and not gg_n[ns:].any() and not gr_n[:, ns:].any()
+
+
 def test_hash_encoder_single_feature_levels():
     """level_dim = 1 (the reference's kernels are instantiated for 1, 2, 4, 8): forward with dy_dx and the first-order
     backward, atomic and binned; the second-order kernels need C > 1 in the reference too (hashencoder.cu:431)."""
