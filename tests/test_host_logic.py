@@ -211,3 +211,26 @@ def test_tolerance_table_is_frozen_and_bounded(capsys):
     with capsys.disabled():
         print('\ntolerance table: %d entries; fp32 core above 1e-4: %d (all within 2 x the reference yardstick or with a '
               'hand-written cause: %d hand-written in the whole table)' % (len(table), n_f32, n_hand))
+
+
+def test_flat_gradient_needs_a_zero_fill_only_where_the_reduce_rules_leave_holes():
+    """ops.MlpShared.run_wgrad allocates the flat weight gradient without a zero fill when the reduce rules store to
+    every element (WgradProgram.writes_every_element): true for the networks of the reference's configurations, false
+    for the fork's "MLP" configuration of the grid class, whose inactive grid-feature columns no rule writes."""
+    import bench
+    from oracle import config
+    from monosdf_amd import plan as planlib
+    from monosdf_amd.conf import ConfigTree
+    from monosdf_amd.model.network import MonoSDFNetwork
+    confs = {'mlp': bench.model_conf(), 'grid': bench.model_conf(grid=True),
+             'gridless': ConfigTree.from_dict(config.gridless_config(128, 8, 0.1))}
+    got = {}
+    for name, cf in confs.items():
+        m = MonoSDFNetwork(cf)
+        for net in (m.implicit_network, m.rendering_network):
+            mp = net._build_plan()
+            build = planlib.build_sdf_wgrad if mp.kind == 'sdf' else planlib.build_color_wgrad
+            prog = planlib.balanced_program(build, mp, 64 * 40)
+            got[(name, mp.kind)] = prog.writes_every_element(mp.n_w + mp.n_b, mp.maps_np)
+    assert got == {('mlp', 'sdf'): True, ('mlp', 'color'): True, ('grid', 'sdf'): True, ('grid', 'color'): True,
+                   ('gridless', 'sdf'): False, ('gridless', 'color'): True}, got
