@@ -485,7 +485,7 @@ def main(argv=None):
         P = P_main + P_eik
         hbm = {     # algorithmic bytes per launch: 4 B x slots read or written per point
             'msdf_sdf_fwd_grad': 4.0 * P * (3 * hs),               # H written, H re-read, PM written
-            'msdf_sdf_backward': 4.0 * P * (5 * hs + qs + ab),     # H x2, PM, T read; T, QB, AB written
+            'msdf_sdf_backward': 4.0 * P * (4 * hs + qs + ab),     # H x2, PM, q-bar rows read; QB, AB written
         }
         # dominant = the largest per-LAUNCH duration among the kernels with a FLOP model (the sampler's forward
         # kernel runs once per round; per launch it is the smallest of the three)

@@ -198,7 +198,8 @@ typedef struct {
   const float* H;
   const float* PM;
   float* QB;               /* [qsum * P_pad] */
-  float* T;                /* [hsum * P_pad] */
+  float* T;                /* unused (may be NULL): the second-order term 100 (1 - s) p p-bar is formed again in the
+                              sweep down from PM and the stored q-bar rows instead of being written and re-read */
   float* AB;               /* [absum * P_pad] */
   float* GSDF;             /* [P_pad] */
   float* QLAST;            /* [P_pad, 16*kt_last] */

@@ -143,70 +143,69 @@ struct GradSweepHooks {
   __device__ __forceinline__ void drain() { st.issue(); }
 };
 
-// sweep up of the double backward: p-bar -> q-bar = s p-bar in place, t = 100 (1 - s) p p-bar saved to T
+// sweep up of the double backward: p-bar -> q-bar = s p-bar in place.  The second-order term t = 100 (1 - s) p p-bar
+// is NOT stored: the sweep down forms it again from q-bar (which the next layer's input store keeps anyway) as
+// 100 (1 - s) p q-bar / s -- one store of a 1 KB row per layer and point less, and no PM read here.
 struct SweepUpHooks {
   const float* H;
-  const float* PM;
   int ot;
-  v4f h0, h1, p0, p1;
-  PendingStores st;
-  __device__ __forceinline__ SweepUpHooks(const float* H_, const float* PM_, float* T, const int ot_)
-      : H(H_), PM(PM_), ot(ot_) { st.dst = T; st.n = 0; st.t0 = 0; }
+  v4f h0, h1;
+  __device__ __forceinline__ SweepUpHooks(const float* H_, const int ot_) : H(H_), ot(ot_) {}
   __device__ __forceinline__ void pre(const int o0, const int o1) {
-    st.issue();
     const int c0 = o0 < ot ? o0 : ot - 1, c1 = o1 < ot ? o1 : ot - 1;
     h0 = *(const v4f*)(H + 16 * c0);
     h1 = *(const v4f*)(H + 16 * c1);
-    p0 = *(const v4f*)(PM + 16 * c0);
-    p1 = *(const v4f*)(PM + 16 * c1);
   }
-  static __device__ __forceinline__ void tile(const v4f h, const v4f p, v4f& a, v4f& tt) {
+  __device__ __forceinline__ void post(const int, const int, const bool pair, v4f& a0, v4f& a1) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float u = one_minus_sigmoid_from_h(h[r]);
-      const float pb = a[r];
-      tt[r] = 100.0f * u * p[r] * pb;   // s-bar * softplus''  with  p = s q
-      a[r] = (1.0f - u) * pb;
-    }
-  }
-  __device__ __forceinline__ void post(const int o0, const int, const bool pair, v4f& a0, v4f& a1) {
-    tile(h0, p0, a0, st.s0);
-    st.t0 = o0; st.n = 1;
+    for (int r = 0; r < 4; ++r) a0[r] = (1.0f - one_minus_sigmoid_from_h(h0[r])) * a0[r];
     if (pair) {
-      tile(h1, p1, a1, st.s1);
-      st.n = 2;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a1[r] = (1.0f - one_minus_sigmoid_from_h(h1[r])) * a1[r];
     }
   }
-  __device__ __forceinline__ void drain() { st.issue(); }
+  __device__ __forceinline__ void drain() {}
 };
 
-// sweep down: h-bar -> a-bar = h-bar s + t in place, saved to AB.  Tiles >= ot are left alone (ot == 0: none).
+// sweep down: h-bar -> a-bar = h-bar s + t in place, saved to AB, with t = 100 (1 - s) p p-bar formed from the saved
+// p (PM) and q-bar = s p-bar (the input rows of the next layer: QB, or QLAST above the last hidden layer) as
+// 100 (1 - s) p q-bar / s; s == 0 means q-bar == 0 and p == 0: t = 0.  Tiles >= ot are left alone (ot == 0: none).
 struct SweepDownHooks {
   const float* H;
-  const float* T;
+  const float* PM;
+  const float* Q;      // q-bar rows of the layer above (same tile order as this layer's outputs)
   int ot;
-  v4f h0, h1, t0, t1;
+  v4f h0, h1, p0, p1, q0, q1;
   PendingStores st;
-  __device__ __forceinline__ SweepDownHooks(const float* H_, const float* T_, float* AB, const int ot_)
-      : H(H_), T(T_), ot(ot_) { st.dst = AB; st.n = 0; st.t0 = 0; }
+  __device__ __forceinline__ SweepDownHooks(const float* H_, const float* PM_, const float* Q_, float* AB, const int ot_)
+      : H(H_), PM(PM_), Q(Q_), ot(ot_) { st.dst = AB; st.n = 0; st.t0 = 0; }
   __device__ __forceinline__ void pre(const int o0, const int o1) {
     st.issue();
     if (ot > 0) {
       const int c0 = o0 < ot ? o0 : ot - 1, c1 = o1 < ot ? o1 : ot - 1;
       h0 = *(const v4f*)(H + 16 * c0);
       h1 = *(const v4f*)(H + 16 * c1);
-      t0 = *(const v4f*)(T + 16 * c0);
-      t1 = *(const v4f*)(T + 16 * c1);
+      p0 = *(const v4f*)(PM + 16 * c0);
+      p1 = *(const v4f*)(PM + 16 * c1);
+      q0 = *(const v4f*)(Q + 16 * c0);
+      q1 = *(const v4f*)(Q + 16 * c1);
+    }
+  }
+  static __device__ __forceinline__ void tile(const v4f h, const v4f p, const v4f q, v4f& a) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float u = one_minus_sigmoid_from_h(h[r]);
+      const float sg = 1.0f - u;
+      const float pb = (sg > 0.f) ? q[r] * __builtin_amdgcn_rcpf(sg) : 0.f;      // p-bar
+      a[r] = a[r] * sg + 100.0f * u * p[r] * pb;
     }
   }
   __device__ __forceinline__ void post(const int o0, const int o1, const bool pair, v4f& a0, v4f& a1) {
     if (o0 < ot) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) a0[r] = a0[r] * (1.0f - one_minus_sigmoid_from_h(h0[r])) + t0[r];
+      tile(h0, p0, q0, a0);
       st.s0 = a0; st.t0 = o0; st.n = 1;
       if (pair && o1 < ot) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) a1[r] = a1[r] * (1.0f - one_minus_sigmoid_from_h(h1[r])) + t1[r];
+        tile(h1, p1, q1, a1);
         st.s1 = a1; st.n = 2;
       }
     }
@@ -469,8 +468,7 @@ __device__ __forceinline__ void sdf_backward_body(const msdf_plan_t& plan, const
     const size_t off = (size_t)L.hpre * Pp + (size_t)c.pt * (16 * L.ot) + 4 * c.q;
     // the hooks turn p-bar into q-bar of the next layer chunk by chunk, loading H / PM and storing T under the
     // product's own matrix instructions
-    Core::gemm(L.ktp, acc, in, L.ot, (const wvec*)a.wpack + L.wf_off, lds,
-               SweepUpHooks(a.H + off, a.PM + off, a.T + off, L.ot));
+    Core::gemm(L.ktp, acc, in, L.ot, (const wvec*)a.wpack + L.wf_off, lds, SweepUpHooks(a.H + off, L.ot));
 #pragma unroll
     for (int t = 0; t < MT; ++t) in[t] = (t < L.ot) ? acc[t] : V4ZERO;
   }
@@ -509,7 +507,12 @@ __device__ __forceinline__ void sdf_backward_body(const msdf_plan_t& plan, const
   auto down_hooks = [&](const int l) {     // hooks of the product whose output feeds layer l (l < 0: none)
     const msdf_layer_t Ln = plan.layer[l >= 0 ? l : 0];
     const size_t off = (size_t)Ln.hpre * Pp + (size_t)c.pt * (16 * Ln.ot) + 4 * c.q;
-    return SweepDownHooks(a.H + off, a.T + off,
+    // q-bar of layer l's outputs = the input rows stored for layer l + 1 (QLAST above the last hidden layer)
+    const int ln = (l >= 0 ? l : 0) + 1;
+    const msdf_layer_t Lq = plan.layer[ln];
+    const float* Q = (ln == nl - 1) ? a.QLAST + (size_t)c.pt * (16 * Lq.kt) + 4 * c.q
+                                    : a.QB + (size_t)Lq.qpre * Pp + (size_t)c.pt * (16 * Lq.kt) + 4 * c.q;
+    return SweepDownHooks(a.H + off, a.PM + off, Q,
                           a.AB + (size_t)Ln.abpre * Pp + (size_t)c.pt * (16 * Ln.ot) + 4 * c.q, l >= 0 ? Ln.ot : 0);
   };
   Core::gemm(LL.otp, acc, in, LL.kt, (const wvec*)a.wpack + LL.wb_off, lds, down_hooks(nl - 2));

@@ -357,8 +357,9 @@ class SdfMlpFunction(torch.autograd.Function):
         b.g_raux = g_raux.data_ptr() if (g_raux is not None and ctx.has_aux) else None
         b.clamped = clamped.data_ptr()
         base = ws.data_ptr()
-        for k in ('H', 'PM', 'QB', 'T', 'AB', 'GSDF', 'QLAST'):
+        for k in ('H', 'PM', 'QB', 'AB', 'GSDF', 'QLAST'):
             setattr(b, k, base + 4 * woff[k])
+        b.T = None           # the second-order term is formed again in the sweep down: no buffer
         b.g_aux = g_aux.data_ptr() if g_aux is not None else None
         if P > 0:
             _lib.call('msdf_sdf_backward', C.byref(plan), C.byref(b), _lib.stream_ptr())

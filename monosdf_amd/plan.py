@@ -255,7 +255,7 @@ def sdf_workspace(mp, P_pad):
     P = mp.plan
     n = P.n_layers
     sizes = [('H', P.hsum * P_pad), ('PM', P.hsum * P_pad), ('IN0', 16 * mp.in0_tiles * P_pad),
-             ('QB', P.qsum * P_pad), ('T', P.hsum * P_pad), ('AB', P.absum * P_pad),
+             ('QB', P.qsum * P_pad), ('AB', P.absum * P_pad),
              ('GSDF', P_pad), ('QLAST', 16 * P.layer[n - 1].kt * P_pad)]
     off, total = {}, 0
     for k, s in sizes:
