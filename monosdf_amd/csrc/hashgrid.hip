@@ -221,27 +221,24 @@ hg_node_forward_kernel(const float* __restrict__ x, const float inv_divide, floa
 }
 
 // inout[b,d] += scale * sum_{l,c} g[b, l C + c] * dy_dx[l,b,d,c]   (the grid part of d sdf / d x, chain rule factor in)
+// One thread per (point, input dimension) -- consecutive lanes read consecutive 8-byte (C = 2) pieces of dy_dx and write
+// consecutive floats; the sum over (level, channel) runs in the reference's order (hashencoder.cu:347-372, also one thread per (b, d)).
 template <int C>
 __global__ void __launch_bounds__(HG_THREADS)
 hg_node_input_gradient_kernel(const float* __restrict__ g, const uint32_t pitch, const float* __restrict__ dy_dx,
                               const uint32_t B, const uint32_t L, const float scale, float* __restrict__ inout) {
-  const uint32_t b = blockIdx.x * HG_THREADS + threadIdx.x;
-  if (b >= B) return;
-  float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+  const uint32_t t = blockIdx.x * HG_THREADS + threadIdx.x;
+  if (t >= 3 * B) return;
+  const uint32_t b = t / 3, d = t - 3 * b;
+  float r = 0.f;
+#pragma unroll 8
   for (uint32_t l = 0; l < L; ++l) {
-    const float* dy = dy_dx + ((size_t)l * B + b) * 3 * C;
+    const float* dy = dy_dx + ((size_t)l * B + b) * 3 * C + d * C;
+    const float* gp = pitch ? g + (size_t)b * pitch + l * C : g + ((size_t)l * B + b) * C;
 #pragma unroll
-    for (int ch = 0; ch < C; ++ch) {
-      const float gv = pitch ? g[(size_t)b * pitch + l * C + ch] : g[((size_t)l * B + b) * C + ch];
-      r0 += gv * dy[0 * C + ch];
-      r1 += gv * dy[1 * C + ch];
-      r2 += gv * dy[2 * C + ch];
-    }
+    for (int ch = 0; ch < C; ++ch) r += gp[ch] * dy[ch];
   }
-  const float t0 = r0 * scale, t1 = r1 * scale, t2 = r2 * scale;       // rounded products, then the sums (as the tensor
-  inout[(size_t)b * 3 + 0] += t0;                                       // expression nrm + through * k rounds them)
-  inout[(size_t)b * 3 + 1] += t1;
-  inout[(size_t)b * 3 + 2] += t2;
+  inout[t] += r * scale;      // the rounded product, then the sum (as the tensor expression nrm + through * k rounds them)
 }
 
 // gg[b] = scale * (b < n_split ? g_a[b] : g_b[b - n_split])  (a missing part is zero), stored once;
@@ -1366,7 +1363,8 @@ extern "C" int msdf_hash_node_input_gradient(const float* g, uint32_t pitch, con
                                              uint32_t C, uint32_t L, float scale, float* inout, void* stream) {
   if ((pitch != 0 && pitch < L * C) || g == nullptr || dy_dx == nullptr || inout == nullptr) return MSDF_ERR_ARG;
   if (B == 0) return MSDF_OK;
-  HG_DISPATCH_C(C, (hg_node_input_gradient_kernel<CC><<<(B + HG_THREADS - 1) / HG_THREADS, HG_THREADS, 0,
+  if ((uint64_t)B * 3 >= (1ull << 32)) return MSDF_ERR_UNSUPPORTED;
+  HG_DISPATCH_C(C, (hg_node_input_gradient_kernel<CC><<<(3 * B + HG_THREADS - 1) / HG_THREADS, HG_THREADS, 0,
                                                         (hipStream_t)stream>>>(g, pitch, dy_dx, B, L, scale, inout)));
   return msdf_check_launch();
 }
