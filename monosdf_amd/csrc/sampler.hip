@@ -210,7 +210,11 @@ __global__ void __launch_bounds__(64 * SMP_WAVES) smp_beta_k(const SmpArgs a) {
   if (a.dbg_err0 != nullptr && lane_id() == 0) a.dbg_err0[ray] = e0;
   if (e0 <= a.eps) beta = beta0;
   float lo = beta0, hi = beta;
-  for (int it = 0; it < a.beta_iters; ++it) {
+  // a ray already inside the bound at beta0 has lo == hi == beta0: every bisection step would evaluate the bound at
+  // beta0 again and leave hi where it is (the reference bisects all rays and masks, ray_sampler.py:152-167) --
+  // one wave is one ray, so skipping them is a uniform branch
+  const int iters = (e0 <= a.eps) ? 0 : a.beta_iters;
+  for (int it = 0; it < iters; ++it) {
     const float mid = (lo + hi) / 2.0f;
     const float e = smp_error_bound(l, a.M, mid);
     if (e <= a.eps) hi = mid;
