@@ -22,7 +22,7 @@ round) on the fp32 MFMA core, with `roofline` (dominant kernel, HIP-event timed 
 BASELINE.md section 3, rank 0, N=1 only).  Beside it, never mixed into `value` (N=1 only):
 `sharp_state` = the same step at density beta 0.01, where the sampler needs 2+ rounds, with the
 rounds per step and what the speculation of the round count cost; `hash_grid` = configs[2] with its HBM roofline;
-`alt_matrix_core` = the bf16x3 core; `sustained` = 400 consecutive Adam steps from random init, a fresh ray batch
+`alt_matrix_core` = the bf16x3 core, `alt_matrix_core_x6` = the bf16x6 core; `sustained` = 400 consecutive Adam steps from random init, a fresh ray batch
 every step (what training costs once beta moves and the sampler needs more rounds).
 """
 import argparse
@@ -143,13 +143,18 @@ def cpu_baseline():
 def pmc_traffic(entry, precision):
     """HBM bytes per launch of `entry` from the committed rocprofv3 --pmc summary (FETCH_SIZE x2 + WRITE_SIZE per the
     gfx950 note of MI355X_MICROARCH.md; scripts/pmc_sum.py) -> (bytes or None, file name or None)."""
-    kernel = entry.replace('_if', '') + ('_k' if precision == 'fp32' else '_b16_k')
+    base = entry.replace('_if', '')
+    # the bf16 kernels are templates on the number of planes: "void msdf_..._b16_k<2>" (bf16x3) / "<3>" (bf16x6)
+    names = {'fp32': [base + '_k'], 'bf16x3': ['void %s_b16_k<2>' % base, base + '_b16_k'],
+             'bf16x6': ['void %s_b16_k<3>' % base]}[precision]
     for name in ('r03_pmc_%s.json' % precision, 'r02_pmc_%s.json' % precision, 'r01_v8_pmc_%s.json' % precision):
         path = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(path):
-            row = json.load(open(path)).get(kernel)
-            if row and 'hbm_bytes_per_launch_corrected' in row:
-                return row['hbm_bytes_per_launch_corrected'], 'profiles/' + name
+            table = json.load(open(path))
+            for kernel in names:
+                row = table.get(kernel)
+                if row and 'hbm_bytes_per_launch_corrected' in row:
+                    return row['hbm_bytes_per_launch_corrected'], 'profiles/' + name
     return None, None
 
 
@@ -235,7 +240,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--config', choices=['mlp', 'grid'], default='mlp',
                     help="mlp = BASELINE.json configs[1] (the headline metric); grid = configs[2] alone")
-    ap.add_argument('--precision', choices=['fp32', 'bf16x3'], default=os.environ.get('MONOSDF_PRECISION', 'fp32'),
+    ap.add_argument('--precision', choices=['fp32', 'bf16x3', 'bf16x6'], default=os.environ.get('MONOSDF_PRECISION', 'fp32'),
                     help='matrix core of the fused MLP kernels that `value` is measured on (default fp32 MFMA)')
     ap.add_argument('--no-alt-precision', dest='alt_precision', action='store_false',
                     help='skip the measurement on the other matrix core (reported under alt_matrix_core)')
@@ -514,13 +519,15 @@ def main(argv=None):
     extras = args.extras and single and not grid_only
     sharp = measure(args.precision, beta=0.01) if extras else None
     alt = measure('bf16x3' if args.precision == 'fp32' else 'fp32') if (extras and args.alt_precision) else None
+    alt6 = measure('bf16x6') if (extras and args.alt_precision and args.precision == 'fp32') else None
     # the hash-grid configuration: beside the headline at N = 1, and at N > 1 for its gradient exchange
     grid = measure('fp32', grid=True) if (extras or (use_dist and args.extras and not grid_only)) else None
     sustained = measure(args.precision, steps=args.sustained_steps, fresh=True) \
         if (extras and args.sustained_steps > 0) else None
 
     if rank == 0:
-        dtype = 'f32' if args.precision == 'fp32' else 'bf16x3 (fp32 split into 2 bf16, fp32 accumulate)'
+        dtype = {'fp32': 'f32', 'bf16x3': 'bf16x3 (fp32 split into 2 bf16, 3 products, fp32 accumulate)',
+                 'bf16x6': 'bf16x6 (fp32 split into 3 bf16, 6 products, fp32 accumulate)'}[args.precision]
         if grid_only:
             res = grid_report(args, primary['kern'], primary['dt'], world, primary['sampler']['mean_rounds'],
                               primary['loss'], primary['sampler'])
@@ -587,6 +594,17 @@ def main(argv=None):
                 'kernels_ms_per_step': ms(alt),
                 'note': 'same workload, steps and warm-up on the other matrix core of the fused MLP kernels (opt-in: '
                         'narrower arithmetic than the reference); `value` above is the %s core' % args.precision,
+            }
+        if alt6 is not None:
+            a6mf, a6hb = mlp_rooflines(alt6)
+            res['alt_matrix_core_x6'] = {
+                'matrix_core': 'bf16x6', 'value': rate(alt6), 'unit': 'rays/s',
+                'ms_per_step': 1e3 * alt6['dt'] / args.steps, 'roofline': a6hb or a6mf,
+                'kernels_ms_per_step': ms(alt6),
+                'note': 'same workload, steps and warm-up with every operand of the fused MLP kernels split into THREE bf16 '
+                        'planes and six products per term (fp32 accumulation): fp32-grade results -- its parity tests are '
+                        'held to the fp32 core\'s rows of the frozen tolerance table -- on the bf16 matrix cores; weight '
+                        'gradients on the fp32 kernel.  Opt-in; `value` above is the fp32 MFMA core',
             }
         if single and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline()

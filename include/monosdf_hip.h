@@ -128,7 +128,9 @@ int msdf_hash_node_scatter(const float* grad_first, const float* grad_second, ui
 /* ---- fused MLPs ----
  * Every entry point that takes a plan runs on the matrix core named by plan->precision (monosdf_plan.h):
  * MSDF_PRECISION_F32 = fp32 MFMA; MSDF_PRECISION_BF16X3 = each product as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi
- * on the bf16 matrix cores with fp32 accumulation (~1e-5 relative error, measured in tests/).  The two use
+ * on the bf16 matrix cores with fp32 accumulation (~1e-5 relative error, measured in tests/); MSDF_PRECISION_BF16X6 =
+ * three bf16 planes per operand and the six cross terms down to 2^-16 of the product (fp32-grade: its parity tests
+ * are held to the fp32 core's tolerances; msdf_wgrad runs the fp32 kernel for it).  The cores use
  * different weight packs: `wpack` is opaque, sized by the host (monosdf_amd/plan.py) and produced by
  * msdf_pack_weights for the same plan. */
 int msdf_pack_weights(const msdf_plan_t* plan, const msdf_packrule_t* rules_dev, const int* maps_dev,

@@ -15,6 +15,7 @@
 
 #define MSDF_PRECISION_F32 0
 #define MSDF_PRECISION_BF16X3 1
+#define MSDF_PRECISION_BF16X6 2   /* three bf16 planes per operand, six products: fp32-grade */
 
 typedef struct {
   int32_t kt;        /* input tiles  (16 slots each) */
@@ -46,8 +47,9 @@ typedef struct {
                            (colour network) -- outputs the kernels form as dot products instead of a matrix product */
   int32_t mode;         /* colour network: 1 = idr input [x, PE(v), n, feat], 0 = nerf [PE(v), feat]; sdf: unused */
   int32_t out_act;      /* colour network: 0 sigmoid, 1 relu (if_hdr) */
-  int32_t precision;    /* MSDF_PRECISION_*: which matrix core the kernels run this plan on.  BF16X3 plans count
-                           K in blocks of 32 slots (ktp / otp) and their wf_off / wb_off address bf16 hi/lo packs */
+  int32_t precision;    /* MSDF_PRECISION_*: which matrix core the kernels run this plan on.  BF16X3 / BF16X6 plans
+                           count K in blocks of 32 slots (ktp / otp) and their wf_off / wb_off address bf16 plane packs
+                           (2 / 3 planes of 1 KB per out tile and k block) */
   int32_t out_rows;     /* rows packed at wsdf_off: slots sdf_slot .. sdf_slot + out_rows - 1 of the last layer */
   msdf_layer_t layer[MSDF_MAX_LAYERS];
 } msdf_plan_t;

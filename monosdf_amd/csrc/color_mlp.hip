@@ -35,7 +35,7 @@ extern "C" int msdf_color_forward(const msdf_plan_t* plan, const msdf_color_fwd_
   if (plan == nullptr || a == nullptr || a->P < 0 || a->spr < 1) return MSDF_ERR_ARG;
   if (a->P == 0) return MSDF_OK;
   if (a->P_pad < a->P || (a->P_pad % MLP_PTS_PER_WG) != 0) return MSDF_ERR_ARG;
-  if (plan->precision == MSDF_PRECISION_BF16X3) return msdf_b16_color_forward(plan, a, (hipStream_t)stream);
+  if (plan->precision == MSDF_PRECISION_BF16X3 || plan->precision == MSDF_PRECISION_BF16X6) return msdf_b16_color_forward(plan, a, (hipStream_t)stream);
   if (color_prepare((const void*)msdf_color_forward_k)) return MSDF_ERR_LAUNCH;
   msdf_color_forward_k<<<a->P_pad / MLP_PTS_PER_WG, MLP_THREADS, MLP_LDS_BYTES, (hipStream_t)stream>>>(*plan, *a);
   return msdf_check_launch();
@@ -45,7 +45,7 @@ extern "C" int msdf_color_backward(const msdf_plan_t* plan, const msdf_color_bwd
   if (plan == nullptr || a == nullptr || a->P < 0) return MSDF_ERR_ARG;
   if (a->P == 0) return MSDF_OK;
   if (a->P_pad < a->P || (a->P_pad % MLP_PTS_PER_WG) != 0) return MSDF_ERR_ARG;
-  if (plan->precision == MSDF_PRECISION_BF16X3) return msdf_b16_color_backward(plan, a, (hipStream_t)stream);
+  if (plan->precision == MSDF_PRECISION_BF16X3 || plan->precision == MSDF_PRECISION_BF16X6) return msdf_b16_color_backward(plan, a, (hipStream_t)stream);
   if (color_prepare((const void*)msdf_color_backward_k)) return MSDF_ERR_LAUNCH;
   msdf_color_backward_k<<<a->P_pad / MLP_PTS_PER_WG, MLP_THREADS, MLP_LDS_BYTES, (hipStream_t)stream>>>(*plan, *a);
   return msdf_check_launch();

@@ -114,7 +114,7 @@ extern "C" int msdf_pack_weights(const msdf_plan_t* plan, const msdf_packrule_t*
                                  const float* flat_w, const float* flat_b, void* wpack, float* bpack,
                                  void* stream) {
   if (plan == nullptr || plan->n_layers < 1 || plan->n_layers > MSDF_MAX_LAYERS) return MSDF_ERR_ARG;
-  if (plan->precision == MSDF_PRECISION_BF16X3)
+  if (plan->precision == MSDF_PRECISION_BF16X3 || plan->precision == MSDF_PRECISION_BF16X6)
     return msdf_b16_pack_weights(plan, rules_dev, maps_dev, flat_w, flat_b, wpack, bpack, (hipStream_t)stream);
   if (plan->precision != MSDF_PRECISION_F32) return MSDF_ERR_ARG;
   const dim3 grid(32, plan->n_layers, 3);
@@ -129,7 +129,7 @@ extern "C" int msdf_sdf_forward_if(const msdf_plan_t* plan, const void* wpack, c
   if (plan == nullptr || P < 0) return MSDF_ERR_ARG;
   if (P == 0) return MSDF_OK;
   if (plan->aux_tiles > 0 && aux == nullptr) return MSDF_ERR_ARG;
-  if (plan->precision == MSDF_PRECISION_BF16X3)
+  if (plan->precision == MSDF_PRECISION_BF16X3 || plan->precision == MSDF_PRECISION_BF16X6)
     return msdf_b16_sdf_forward(plan, wpack, bpack, x, aux, P, clamp_radius, sphere_scale, sdf, run_flag,
                                 (hipStream_t)stream);
   if (mlp_prepare((const void*)msdf_sdf_forward_k)) return MSDF_ERR_LAUNCH;
@@ -150,7 +150,7 @@ extern "C" int msdf_sdf_fwd_grad(const msdf_plan_t* plan, const msdf_fg_args_t* 
   if (a->P == 0) return MSDF_OK;
   if (a->P_pad < a->P || (a->P_pad % MLP_PTS_PER_WG) != 0) return MSDF_ERR_ARG;
   if (plan->aux_tiles > 0 && a->aux == nullptr) return MSDF_ERR_ARG;
-  if (plan->precision == MSDF_PRECISION_BF16X3) return msdf_b16_sdf_fwd_grad(plan, a, (hipStream_t)stream);
+  if (plan->precision == MSDF_PRECISION_BF16X3 || plan->precision == MSDF_PRECISION_BF16X6) return msdf_b16_sdf_fwd_grad(plan, a, (hipStream_t)stream);
   if (mlp_prepare((const void*)msdf_sdf_fwd_grad_k)) return MSDF_ERR_LAUNCH;
   msdf_sdf_fwd_grad_k<<<a->P_pad / MLP_PTS_PER_WG, MLP_THREADS, MLP_LDS_BYTES, (hipStream_t)stream>>>(*plan, *a);
   return msdf_check_launch();
@@ -160,7 +160,7 @@ extern "C" int msdf_sdf_backward(const msdf_plan_t* plan, const msdf_bw_args_t* 
   if (plan == nullptr || a == nullptr || a->P < 0) return MSDF_ERR_ARG;
   if (a->P == 0) return MSDF_OK;
   if (a->P_pad < a->P || (a->P_pad % MLP_PTS_PER_WG) != 0) return MSDF_ERR_ARG;
-  if (plan->precision == MSDF_PRECISION_BF16X3) return msdf_b16_sdf_backward(plan, a, (hipStream_t)stream);
+  if (plan->precision == MSDF_PRECISION_BF16X3 || plan->precision == MSDF_PRECISION_BF16X6) return msdf_b16_sdf_backward(plan, a, (hipStream_t)stream);
   if (mlp_prepare((const void*)msdf_sdf_backward_k)) return MSDF_ERR_LAUNCH;
   msdf_sdf_backward_k<<<a->P_pad / MLP_PTS_PER_WG, MLP_THREADS, MLP_LDS_BYTES, (hipStream_t)stream>>>(*plan, *a);
   return msdf_check_launch();

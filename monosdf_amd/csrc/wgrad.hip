@@ -419,7 +419,9 @@ extern "C" int msdf_wgrad(const msdf_wgrad_item_t* items_dev, const int32_t* wg_
                                                                                P_pad);
     return msdf_check_launch();
   }
-  if (precision != MSDF_PRECISION_F32) return MSDF_ERR_ARG;
+  // BF16X6 networks take the fp32 kernel: both operands are saved fp32 activations, a three-plane image of a stage
+  // would not fit the LDS double buffer, and the fp32 matrix instructions are exact where bf16x6 is fp32-grade
+  if (precision != MSDF_PRECISION_F32 && precision != MSDF_PRECISION_BF16X6) return MSDF_ERR_ARG;
   if (hipFuncSetAttribute((const void*)msdf_wgrad_k, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS_BYTES) !=
       hipSuccess)
     return MSDF_ERR_LAUNCH;

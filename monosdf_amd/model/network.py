@@ -53,7 +53,7 @@ class _FusedNet(nn.Module):
     def _layers(self):
         return [getattr(self, 'lin%d' % l) for l in range(self.num_layers - 1)]
 
-    # matrix core of the fused kernels: 'fp32' (default) or 'bf16x3'.  Not a reference option: set it with
+    # matrix core of the fused kernels: 'fp32' (default), 'bf16x3' or 'bf16x6' (ops.PRECISIONS).  Not a reference option: set it with
     # set_precision() / MonoSDFNetwork.set_precision() or the MONOSDF_PRECISION environment variable.
     precision = None
     supports_bf16x3 = False
@@ -369,7 +369,7 @@ class MonoSDFNetwork(nn.Module):
         self.speculate_rounds = False if env == '0' else ('all' if env == 'all' else True)
 
     def set_precision(self, precision):
-        """'fp32' or 'bf16x3' matrix core for the fused MLP kernels (not a reference option)."""
+        """'fp32', 'bf16x3' or 'bf16x6' matrix core for the fused MLP kernels (not a reference option)."""
         self.implicit_network.set_precision(precision)
         self.rendering_network.set_precision(precision)
         return self

@@ -27,7 +27,8 @@ def _pad64(n):
 
 
 # matrix core of the fused MLP kernels (include/monosdf_plan.h MSDF_PRECISION_*)
-PRECISIONS = ('fp32', 'bf16x3')
+PRECISIONS = ('fp32', 'bf16x3', 'bf16x6')      # index = MSDF_PRECISION_*
+_PLANES = {'bf16x3': 2, 'bf16x6': 3}
 
 
 # ---------------------------------------------------------------------------
@@ -93,7 +94,7 @@ class FusedMlp:
         self.device = device
         self.precision = precision
         # the plan the kernels get: same geometry, K counts / pack offsets of the chosen matrix core
-        self.plan = mlp_plan.plan if precision == 'fp32' else mlp_plan.build_b16()
+        self.plan = mlp_plan.plan if precision == 'fp32' else mlp_plan.build_b16(_PLANES[precision])
         self.rules_dev = torch.from_numpy(mlp_plan.rules_np).to(device)
         self.maps_dev = torch.from_numpy(mlp_plan.maps_np).to(device)
         self._wgrad_cache = {}
@@ -106,7 +107,7 @@ class FusedMlp:
         flat_w = _need_cuda(flat_w.detach(), 'weights')
         flat_b = _need_cuda(flat_b.detach(), 'biases')
         assert flat_w.numel() == mp.n_w and flat_b.numel() == mp.n_b
-        units16 = mp.wpack_f4 if self.precision == 'fp32' else mp.wpack16_v8
+        units16 = mp.wpack_f4 if self.precision == 'fp32' else mp.wpack16_units(_PLANES[self.precision])
         wpack = torch.empty(units16 * 4 + 4 * 17 * 64 * 4, device=self.device, dtype=torch.float32)
         bpack = torch.empty(mp.bpack_f + 64, device=self.device, dtype=torch.float32)
         _lib.call('msdf_pack_weights', C.byref(self.plan), _lib.ptr(self.rules_dev), _lib.ptr(self.maps_dev),

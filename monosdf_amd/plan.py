@@ -84,14 +84,15 @@ class MlpPlan:
         self.colmaps.append((r.colmap_off, colmap))
         return u
 
-    def build_b16(self):
-        """Second plan for the bf16x3 kernels: ktp / otp = K-block counts (32 slots), wf_off / wb_off =
-        16-byte offsets of the hi/lo packs; everything else identical."""
-        if getattr(self, 'plan16', None) is not None:
-            return self.plan16
+    def build_b16(self, planes=2):
+        """Second plan for the bf16-split kernels (planes = 2: bf16x3, 3: bf16x6): ktp / otp = K-block counts (32 slots),
+        wf_off / wb_off = 16-byte offsets of the plane packs; everything else identical."""
+        cache = self.__dict__.setdefault('_plans16', {})
+        if planes in cache:
+            return cache[planes][0]
         p16 = _lib.Plan()
         C.memmove(C.byref(p16), C.byref(self.plan), C.sizeof(_lib.Plan))
-        p16.precision = 1            # MSDF_PRECISION_BF16X3
+        p16.precision = {2: 1, 3: 2}[planes]            # MSDF_PRECISION_BF16X3 / MSDF_PRECISION_BF16X6
         off = 0
         for u in range(self.plan.n_layers):
             L = p16.layer[u]
@@ -99,12 +100,16 @@ class MlpPlan:
             kb = lambda t: 8 if 6 <= (t + 1) // 2 <= 8 else (t + 1) // 2
             L.ktp, L.otp = kb(L.kt), kb(L.ot)
             L.wf_off = off
-            off += (L.ot + 3) // 4 * 4 * L.ktp * 2 * 64      # out tiles padded to the 4-tile LDS chunk
+            off += (L.ot + 3) // 4 * 4 * L.ktp * planes * 64      # out tiles padded (the kernels stage whole chunks)
             L.wb_off = off
-            off += (L.kt + 3) // 4 * 4 * L.otp * 2 * 64
-        self.plan16 = p16
-        self.wpack16_v8 = off
+            off += (L.kt + 3) // 4 * 4 * L.otp * planes * 64
+        cache[planes] = (p16, off)
         return p16
+
+    def wpack16_units(self, planes=2):
+        """16-byte units of the plane packs of build_b16(planes)."""
+        self.build_b16(planes)
+        return self._plans16[planes][1]
 
     def finalise(self):
         # flat weight / bias buffers are the concatenation of the original tensors

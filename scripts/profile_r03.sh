@@ -1,5 +1,5 @@
 # Round-3 profiles of bench.py (both configs): rocprofv3 kernel stats + PMC passes -> gpurun_out/r03prof/
-#   gpurun --timeout 1100 -- 'bash scripts/profile_r03.sh [mlp|grid|"mlp grid"]'
+#   gpurun --timeout 1100 -- 'bash scripts/profile_r03.sh [mlp|grid|b16|b16x6 ...]'
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -7,7 +7,9 @@ O=$R/gpurun_out/r03prof
 mkdir -p $O
 B="python3 $R/bench.py --no-extras --no-cpu-baseline --no-alt-precision"
 for cfg in ${1:-mlp grid}; do
-  EXTRA=""; [ "$cfg" = b16 ] && EXTRA="--precision bf16x3" && CFG=mlp || CFG=$cfg
+  EXTRA=""; CFG=$cfg
+  [ "$cfg" = b16 ] && EXTRA="--precision bf16x3" && CFG=mlp
+  [ "$cfg" = b16x6 ] && EXTRA="--precision bf16x6" && CFG=mlp
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$cfg -- $B --steps 10 --warmup 3 --config $CFG $EXTRA > $O/bench_under_rocprof_$cfg.json 2>/dev/null
   cp $O/stats_$cfg/*/*kernel_stats.csv $O/kernel_stats_$cfg.csv
   cp $O/stats_$cfg/*/*kernel_trace.csv $O/kernel_trace_$cfg.csv

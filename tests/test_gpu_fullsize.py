@@ -32,7 +32,7 @@ def _step(model, rays, seed=7):
     return out, loss
 
 
-@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3', 'bf16x6'])
 def test_fullsize_compositing_identities_and_reproducibility(precision):
     model = _model(precision)
     rays = bench.make_rays(N, 1, 'cuda')
