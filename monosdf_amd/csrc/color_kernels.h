@@ -142,8 +142,12 @@ __device__ __forceinline__ void color_forward_body(const msdf_plan_t& plan, cons
 #pragma unroll
   for (int t = 0; t < MT; ++t)
     in[t] = (t < U0.kt) ? *(const v4f*)(a.feat + (size_t)ptc * (16 * U0.kt) + 16 * t + 4 * q) : V4ZERO;
-  load_bias_c(acc, a.bpack + U0.bias_off, U0.ot, q);
-  Core::gemm(U0.ktp, acc, in, U0.ot, (const wvec*)a.wpack + U0.wf_off, lds, NoHooks());
+  if constexpr (Core::BIAS_IN_HOOKS) {
+    Core::gemm_bias(U0.ktp, acc, in, U0.ot, (const wvec*)a.wpack + U0.wf_off, lds, NoHooks(), a.bpack + U0.bias_off + 4 * q);
+  } else {
+    load_bias_c(acc, a.bpack + U0.bias_off, U0.ot, q);
+    Core::gemm(U0.ktp, acc, in, U0.ot, (const wvec*)a.wpack + U0.wf_off, lds, NoHooks());
+  }
   // ---- first layer, misc part (same accumulators)
   {
     v4f m[5];
@@ -172,8 +176,13 @@ __device__ __forceinline__ void color_forward_body(const msdf_plan_t& plan, cons
     const msdf_layer_t L = plan.layer[u];
 #pragma unroll
     for (int t = 0; t < MT; ++t) in[t] = (t < L.kt) ? acc[t] : V4ZERO;
-    load_bias_c(acc, a.bpack + L.bias_off, L.ot, q);
-    Core::gemm(L.ktp, acc, in, L.ot, (const wvec*)a.wpack + L.wf_off, lds, next_hooks(u + 1));
+    if constexpr (Core::BIAS_IN_HOOKS) {
+      Core::gemm_bias(L.ktp, acc, in, L.ot, (const wvec*)a.wpack + L.wf_off, lds, next_hooks(u + 1),
+                      a.bpack + L.bias_off + 4 * q);
+    } else {
+      load_bias_c(acc, a.bpack + L.bias_off, L.ot, q);
+      Core::gemm(L.ktp, acc, in, L.ot, (const wvec*)a.wpack + L.wf_off, lds, next_hooks(u + 1));
+    }
   }
   // ---- output layer: rgb_c = w_c . relu(h) + b_c over the register-resident activation (a 16-row matrix tile
   // with 13 rows of zeros would be one dependent chain of 64 matrix instructions behind a weight chunk of its own)

@@ -238,8 +238,12 @@ __device__ __forceinline__ void sdf_forward_body(const msdf_plan_t& plan, const 
       load_input_tiles(in0, plan, aux, c);
       place_tiles(in, L.skip_tile, in0, in0_tiles);
     }
-    load_bias(acc, bpack + L.bias_off, L.ot, c.q);
-    Core::gemm(L.ktp, acc, in, L.ot, wpack + L.wf_off, lds, SoftplusHooks<Core>());
+    if constexpr (Core::BIAS_IN_HOOKS) {
+      Core::gemm_bias(L.ktp, acc, in, L.ot, wpack + L.wf_off, lds, SoftplusHooks<Core>(), bpack + L.bias_off + 4 * c.q);
+    } else {
+      load_bias(acc, bpack + L.bias_off, L.ot, c.q);
+      Core::gemm(L.ktp, acc, in, L.ot, wpack + L.wf_off, lds, SoftplusHooks<Core>());
+    }
 #pragma unroll
     for (int t = 0; t < MT; ++t) in[t] = (t < L.ot) ? acc[t] : V4ZERO;
   }
@@ -286,9 +290,14 @@ __device__ __forceinline__ void sdf_fwd_grad_body(const msdf_plan_t& plan, const
       load_input_tiles(in0, plan, a.aux, c);
       place_tiles(in, L.skip_tile, in0, in0_tiles);
     }
-    load_bias(acc, a.bpack + L.bias_off, L.ot, c.q);
     float* Hl = a.H + (size_t)L.hpre * Pp + (size_t)c.pt * (16 * L.ot) + 4 * c.q;
-    Core::gemm(L.ktp, acc, in, L.ot, (const wvec*)a.wpack + L.wf_off, lds, SoftplusSaveHooks<Core>(Hl));
+    if constexpr (Core::BIAS_IN_HOOKS) {
+      Core::gemm_bias(L.ktp, acc, in, L.ot, (const wvec*)a.wpack + L.wf_off, lds, SoftplusSaveHooks<Core>(Hl),
+                      a.bpack + L.bias_off + 4 * c.q);
+    } else {
+      load_bias(acc, a.bpack + L.bias_off, L.ot, c.q);
+      Core::gemm(L.ktp, acc, in, L.ot, (const wvec*)a.wpack + L.wf_off, lds, SoftplusSaveHooks<Core>(Hl));
+    }
 #pragma unroll
     for (int t = 0; t < MT; ++t) in[t] = (t < L.ot) ? acc[t] : V4ZERO;
   }
@@ -296,8 +305,13 @@ __device__ __forceinline__ void sdf_fwd_grad_body(const msdf_plan_t& plan, const
   const msdf_layer_t LL = plan.layer[nl - 1];
   float sdf;
   if (want_feat) {
-    load_bias(acc, a.bpack + LL.bias_off, LL.ot, c.q);
-    Core::gemm(LL.ktp, acc, in, LL.ot, (const wvec*)a.wpack + LL.wf_off, lds, NoHooks());
+    if constexpr (Core::BIAS_IN_HOOKS) {
+      Core::gemm_bias(LL.ktp, acc, in, LL.ot, (const wvec*)a.wpack + LL.wf_off, lds, NoHooks(),
+                      a.bpack + LL.bias_off + 4 * c.q);
+    } else {
+      load_bias(acc, a.bpack + LL.bias_off, LL.ot, c.q);
+      Core::gemm(LL.ktp, acc, in, LL.ot, (const wvec*)a.wpack + LL.wf_off, lds, NoHooks());
+    }
     if (c.valid && c.pt < a.n_feat) {
       float* f = a.feat + (size_t)c.pt * (16 * plan.feat_tiles) + 4 * c.q;
 #pragma unroll
