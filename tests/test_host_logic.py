@@ -234,3 +234,28 @@ def test_flat_gradient_needs_a_zero_fill_only_where_the_reduce_rules_leave_holes
             got[(name, mp.kind)] = prog.writes_every_element(mp.n_w + mp.n_b, mp.maps_np)
     assert got == {('mlp', 'sdf'): True, ('mlp', 'color'): True, ('grid', 'sdf'): True, ('grid', 'color'): True,
                    ('gridless', 'sdf'): False, ('gridless', 'color'): True}, got
+
+
+def test_bf16_plane_plans_share_the_geometry_and_scale_the_pack():
+    """plan.build_b16(planes): same slot geometry as the fp32 plan, K counted in blocks of 32 slots, pack offsets
+    that grow with the number of planes (2: bf16x3, 3: bf16x6), precision = the header's constants."""
+    import re
+    from monosdf_amd import ops, plan as planlib
+    shapes = [(256, 39), (256, 256), (256, 256), (217, 256), (256, 256), (256, 256), (256, 256), (256, 256),
+              (257, 256)]
+    mp = planlib.build_sdf_plan(shapes, [4], 6, 0, False, 256)
+    p2, p3 = mp.build_b16(2), mp.build_b16(3)
+    hdr = open(os.path.join(ROOT, 'include', 'monosdf_plan.h')).read()
+    consts = {k: int(v) for k, v in re.findall(r'#define (MSDF_PRECISION_\w+) (\d+)', hdr)}
+    assert (mp.plan.precision, p2.precision, p3.precision) == (consts['MSDF_PRECISION_F32'],
+                                                               consts['MSDF_PRECISION_BF16X3'],
+                                                               consts['MSDF_PRECISION_BF16X6'])
+    assert ops.PRECISIONS.index('bf16x3') == p2.precision and ops.PRECISIONS.index('bf16x6') == p3.precision
+    assert mp.build_b16(3) is p3                                  # cached per plane count
+    for u in range(mp.plan.n_layers):
+        L, L2, L3 = mp.plan.layer[u], p2.layer[u], p3.layer[u]
+        assert (L2.kt, L2.ot, L3.kt, L3.ot) == (L.kt, L.ot, L.kt, L.ot)
+        assert L2.ktp == L3.ktp >= (L.kt + 1) // 2 and L2.otp == L3.otp >= (L.ot + 1) // 2
+        assert 2 * L3.wf_off == 3 * L2.wf_off and 2 * L3.wb_off == 3 * L2.wb_off
+        assert L3.wb_off - L3.wf_off >= L.ot * L3.ktp * 3 * 64       # room for every out tile's three planes
+    assert 2 * mp.wpack16_units(3) == 3 * mp.wpack16_units(2)
