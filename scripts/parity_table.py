@@ -128,7 +128,8 @@ def write_md(rnd, worst, table, yard, src):
                 continue
             ent = table.get('%s|%s|%s' % (test, case, key))
             if ent is None and '.bf16x6' in test:          # held to the fp32 core's row
-                ent = table.get('%s|%s|%s' % (test.replace('.bf16x6', '.fp32'), case, key))
+                ent = table.get('%s|%s|%s' % (test.replace('.bf16x6', '.fp32'), case, key)) or \
+                table.get('%s|%s|%s' % (test.replace('.bf16x6', ''), case, key))
             y, kind = yardstick(yard, test, case, key)
             ys = '' if y is None else '%.1e (%s)' % (y, kind)
             if ent:
@@ -195,7 +196,8 @@ def main(argv):
             continue
         ent = table.get('%s|%s|%s' % (test, case, key))
         if ent is None and '.bf16x6' in test:              # the bf16x6 core is held to the fp32 core's rows
-            ent = table.get('%s|%s|%s' % (test.replace('.bf16x6', '.fp32'), case, key))
+            ent = table.get('%s|%s|%s' % (test.replace('.bf16x6', '.fp32'), case, key)) or \
+                table.get('%s|%s|%s' % (test.replace('.bf16x6', ''), case, key))
         tol = ent['tol'] if ent else BAR
         if err > tol:
             print('EXCEEDS: %s|%s|%s measured %.2e > %.1e' % (test, case, key, err, tol))

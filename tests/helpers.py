@@ -96,7 +96,8 @@ def tolerance(test, case, key, default=TOL):
     ent = _TABLE.get('%s|%s|%s' % (test, case, key))
     if ent is None and '.bf16x6' in test:
         # the bf16x6 core is held to the fp32 core's rows (a row of its own needs a hand-written cause)
-        ent = _TABLE.get('%s|%s|%s' % (test.replace('.bf16x6', '.fp32'), case, key))
+        ent = _TABLE.get('%s|%s|%s' % (test.replace('.bf16x6', '.fp32'), case, key)) or \
+            _TABLE.get('%s|%s|%s' % (test.replace('.bf16x6', ''), case, key))
     return default if ent is None else float(ent['tol'])
 
 

@@ -26,10 +26,12 @@ def _build(width, depth, precision):
     return conf, state, m.cuda().set_precision(precision)
 
 
+# the bf16x6 core on the generic widths too (run-time K-block counts, chunks of one out tile): same bars, same rows
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x6'])
 @pytest.mark.parametrize('width,depth', SHAPES)
-def test_sdf_network_forward_gradient_and_double_backward(width, depth, errlog):
+def test_sdf_network_forward_gradient_and_double_backward(width, depth, precision, errlog):
     from oracle import monosdf_oracle as mo
-    conf, state, m = _build(width, depth, 'fp32')
+    conf, state, m = _build(width, depth, precision)
     m.train()
     g = torch.Generator().manual_seed(11)
     P = 64 * 3 + 21                                    # ragged last tile
@@ -47,7 +49,8 @@ def test_sdf_network_forward_gradient_and_double_backward(width, depth, errlog):
     loss.backward()
     params = dict(m.named_parameters())
     for n, go in zip(names, g_o):
-        check(errlog, 'shapes_double_backward', '%dx%d' % (depth, width), n, rel_err(params[n].grad, go))
+        check(errlog, 'shapes_double_backward' + ('' if precision == 'fp32' else '.' + precision), '%dx%d' % (depth, width),
+              n, rel_err(params[n].grad, go))
 
 
 @pytest.mark.parametrize('width,depth', [(48, 5), (100, 3), (176, 5)])
