@@ -38,7 +38,7 @@ TABLE = os.path.join(ROOT, 'tests', 'golden', 'tolerances.json')
 YARD = os.path.join(ROOT, 'profiles', 'r03_reference_sensitivity.json')
 B16_FLOOR = 8e-4
 B16_SDF_RATIO = 13.0          # measured |sdf - reference| of the bf16x3 core / the yardstick's 1e-6
-OWN_TOL = ('sampler_rounds', 'stages', 'trajectory')        # tolerances stated in the tests themselves
+OWN_TOL = ('sampler_rounds', 'stages', 'trajectory', 'trajectory.bf16x6')        # tolerances stated in the tests themselves
 KINDS = {'fp64': 'against exact (fp64) arithmetic',
          'perturbed_sdf': "when its sampler's SDF values change by 1e-6 relative",
          'perturbed_sdf_abs': "when its sampler's SDF values change by 1e-6 of max|sdf|"}
