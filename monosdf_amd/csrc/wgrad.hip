@@ -40,6 +40,18 @@ __device__ __forceinline__ void wg_issue_tile(const float* __restrict__ src, con
   }
 }
 
+// The same number of LDS-DMA instructions as wg_issue_tile, all of them the tile's first piece (same bytes, same
+// place, served by the L1): what an item without a Y operand issues instead of a second copy of its X tile.
+__device__ __forceinline__ void wg_issue_first_piece(const float* __restrict__ src, const int ld, const int w,
+                                                     float* dst, const int lane) {
+  const int w4 = w >> 2;
+  const int row = lane / w4, c4 = lane - row * w4;
+#pragma unroll
+  for (int i = 0; i < WG_PIECES; ++i)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)row * ld + 4 * c4),
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+}
+
 __device__ __forceinline__ void wg_wait_outstanding(const int stages_behind) {
   // wait until at most `stages_behind` later stages are still in flight
   static_assert(WG_GLDS_PER_STAGE == 9 && WG_NBUF == 2, "the immediates below are WG_GLDS_PER_STAGE multiples");
@@ -49,10 +61,14 @@ __device__ __forceinline__ void wg_wait_outstanding(const int stages_behind) {
   }
 }
 
-// NARROW is a template parameter, not a branch inside the k loop: with the branch there, the accumulators of
+// The wave grid is a template parameter, not a branch inside the k loop: with the branch there, the accumulators of
 // the two variants met in phi nodes and every k step copied 32 accumulator registers behind an `s_nop 15`
 // that waited out the previous MFMA (a third of the matrix pipe's time).
-template <bool NARROW>
+// NBN == 0: wide items, 2 x 4 waves of 128 rows x 64 columns; NBN = 2, 3, 4: items of <= 32 NBN columns (the PE /
+// PE + hash-feature / skip blocks), 8 x 1 waves of 32 rows x 32 NBN columns so that all four SIMDs work -- an
+// 80-column item on the wide grid keeps the waves of two SIMDs idle and takes as long as a 256-column one.
+// NBN == -1: items of <= 32 rows, 1 x 8 waves of 32 rows x 32 columns.
+template <int NBN>
 __device__ __forceinline__ void wgrad_body(const msdf_wgrad_item_t& it, const int split,
                                            float* __restrict__ part, const int P_pad, float* lds_f) {
   const int n_splits = it.n_splits;
@@ -60,11 +76,14 @@ __device__ __forceinline__ void wgrad_body(const msdf_wgrad_item_t& it, const in
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // wide items: 2 x 4 waves, 128 rows x 64 cols each (4 x 2 MFMA tiles per wave);
-  // narrow items (wy <= 64): 8 x 1 waves, 32 rows x 64 cols each, so all 8 waves (all 4 SIMDs) work
-  constexpr bool narrow = NARROW;
-  const int wi = narrow ? wave : (wave >> 2), wj = narrow ? 0 : (wave & 3);
-  const int i_base = narrow ? 32 * wi : 128 * wi, j_base = 64 * wj;
-  constexpr int na = narrow ? 1 : 4;
+  // narrow items (wy <= 32 NBN): 8 x 1 waves, 32 rows x 32 NBN cols each, so all 8 waves (all 4 SIMDs) work
+  // thin items (wx <= 32 rows, e.g. the colour network's 3-row output layer): 1 x 8 waves, 32 rows x 32 cols each
+  constexpr bool narrow = NBN > 0;
+  constexpr bool thin = NBN < 0;
+  const int wi = thin ? 0 : narrow ? wave : (wave >> 2), wj = thin ? wave : narrow ? 0 : (wave & 3);
+  const int i_base = narrow ? 32 * wi : 128 * wi, j_base = thin ? 32 * wj : 64 * wj;
+  constexpr int na = (narrow || thin) ? 1 : 4;
+  constexpr int nb = thin ? 1 : narrow ? NBN : 2;
 
   // point range of this split, in stages of WG_NP points
   const int n_stages_total = P_pad / WG_NP;
@@ -78,21 +97,21 @@ __device__ __forceinline__ void wgrad_body(const msdf_wgrad_item_t& it, const in
   const float* V = it.v;
   const bool do_mm = it.wy > 0;
 
-  v16f acc[na][2];
+  v16f acc[na][nb];
 #pragma unroll
   for (int a = 0; a < na; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < nb; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   float colsum = 0.f, vrow = 0.f;
 
   // which of this wave's tiles are inside [wx x wy]
-  bool ai[na], bj[2];
+  bool ai[na], bj[nb];
 #pragma unroll
   for (int a = 0; a < na; ++a) ai[a] = (i_base + 32 * a) < it.wx;
 #pragma unroll
-  for (int b = 0; b < 2; ++b) bj[b] = (j_base + 32 * b) < it.wy;
+  for (int b = 0; b < nb; ++b) bj[b] = (j_base + 32 * b) < it.wy;
   const bool wave_active = do_mm && ai[0] && bj[0];
 
   // every wave issues exactly WG_GLDS_PER_STAGE LDS-DMA instructions per stage
@@ -101,7 +120,7 @@ __device__ __forceinline__ void wgrad_body(const msdf_wgrad_item_t& it, const in
     const size_t p0 = (size_t)(s_begin + j) * WG_NP;
     wg_issue_tile(X + p0 * it.x_ld, it.x_ld, it.wx, base, wave, lane);
     if (do_mm) wg_issue_tile(Y + p0 * it.y_ld, it.y_ld, it.wy, base + WG_TILE_F, wave, lane);
-    else wg_issue_tile(X + p0 * it.x_ld, it.x_ld, it.wx, base, wave, lane);
+    else wg_issue_first_piece(X + p0 * it.x_ld, it.x_ld, it.wx, base, lane);   // column sums only: keeps the count uniform
     // per-point scalar (or, without one, a re-copy of 64 floats of X): one 4-byte-per-lane piece
     const float* vsrc = (V != nullptr) ? V + p0 + min(lane, WG_NP - 1) : X + p0 * it.x_ld + min(lane, 15);
     float* vdst = (V != nullptr) ? base + 2 * WG_TILE_F : base + 2 * WG_TILE_F;
@@ -126,11 +145,11 @@ __device__ __forceinline__ void wgrad_body(const msdf_wgrad_item_t& it, const in
       const float* xa = xt + (lane >> 5) * it.wx + i_base + (lane & 31);
       const float* yb = yt + (lane >> 5) * it.wy + j_base + (lane & 31);
       // software-pipelined: the fragments of k-step k+1 are in flight while the 8 MFMAs of step k issue
-      float af[2][na], bf[2][2];
+      float af[2][na], bf[2][nb];
 #pragma unroll
       for (int a = 0; a < na; ++a) af[0][a] = xa[32 * a];
 #pragma unroll
-      for (int b = 0; b < 2; ++b) bf[0][b] = yb[32 * b];
+      for (int b = 0; b < nb; ++b) bf[0][b] = yb[32 * b];
 #pragma unroll
       for (int k = 0; k < WG_NP / 2; ++k) {
         const int cur = k & 1, nxt = cur ^ 1;
@@ -138,13 +157,13 @@ __device__ __forceinline__ void wgrad_body(const msdf_wgrad_item_t& it, const in
 #pragma unroll
           for (int a = 0; a < na; ++a) af[nxt][a] = xa[2 * (k + 1) * it.wx + 32 * a];
 #pragma unroll
-          for (int b = 0; b < 2; ++b) bf[nxt][b] = yb[2 * (k + 1) * it.wy + 32 * b];
+          for (int b = 0; b < nb; ++b) bf[nxt][b] = yb[2 * (k + 1) * it.wy + 32 * b];
         }
         __builtin_amdgcn_sched_barrier(0);   // keep the prefetch above the MFMAs (the scheduler would sink it)
 #pragma unroll
         for (int a = 0; a < na; ++a)
 #pragma unroll
-          for (int b = 0; b < 2; ++b)
+          for (int b = 0; b < nb; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][a], bf[cur][b], acc[a][b], 0, 0, 0);
       }
     }
@@ -164,7 +183,7 @@ __device__ __forceinline__ void wgrad_body(const msdf_wgrad_item_t& it, const in
 #pragma unroll
     for (int a = 0; a < na; ++a) {
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
+      for (int b = 0; b < nb; ++b) {
         if (ai[a] && bj[b]) {
           const int j = j_base + 32 * b + (lane & 31);
 #pragma unroll
@@ -187,9 +206,12 @@ msdf_wgrad_k(const msdf_wgrad_item_t* __restrict__ items, const int* __restrict_
   extern __shared__ float lds_f[];
   const msdf_wgrad_item_t it = items[wg_map[2 * blockIdx.x]];
   const int split = wg_map[2 * blockIdx.x + 1];
-  // wide items: 2 x 4 waves of 128 x 64; narrow items (wy <= 64): 8 x 1 waves of 32 x 64
-  if (it.wy <= 64) wgrad_body<true>(it, split, part, P_pad, lds_f);
-  else wgrad_body<false>(it, split, part, P_pad, lds_f);
+  // wide items: 2 x 4 waves of 128 x 64; items of <= 128 columns: 8 x 1 waves of 32 x (64 | 96 | 128)
+  if (it.wx <= 32 && it.wy > 32) wgrad_body<-1>(it, split, part, P_pad, lds_f);
+  else if (it.wy <= 64) wgrad_body<2>(it, split, part, P_pad, lds_f);
+  else if (it.wy <= 96) wgrad_body<3>(it, split, part, P_pad, lds_f);
+  else if (it.wy <= 128) wgrad_body<4>(it, split, part, P_pad, lds_f);
+  else wgrad_body<0>(it, split, part, P_pad, lds_f);
 }
 
 

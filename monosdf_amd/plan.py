@@ -300,14 +300,24 @@ class WgradProgram:
 
     @staticmethod
     def weight(wx, wy):
-        """Relative duration of one stage: 1 when both waves of a SIMD are busy, 0.5 when <= 4 of the
-        8 waves have a tile, 0 for column-sum-only items."""
+        """Class of an item = the wave grid msdf_wgrad_k runs it on (csrc/wgrad.hip), named by the relative duration of one
+        32-point stage: 1.0 wide (2 x 4 waves of 128 x 64), 0.6 / 0.5 / 0.3 the 8 x 1 grids of <= 128 / 96 / 64 columns,
+        0.2 thin (<= 32 rows: 1 x 8 waves of 32 x 32), 0.0 column sums only."""
         if wy == 0:
             return 0.0
-        if wy <= 64:
-            return 0.3          # narrow mode: 2 MFMAs per k-step and wave instead of 8, then memory latency
-        active = min(2, (wx + 127) // 128) * min(4, (wy + 63) // 64)
-        return 1.0 if active > 4 else 0.5
+        if wx <= 32 and wy > 32:
+            return 0.2
+        if wy <= 128:
+            return {2: 0.3, 3: 0.5, 4: 0.6}[max(2, (wy + 31) // 32)]
+        return 1.0
+
+    # class -> (microseconds per 32-point stage of a workgroup, fixed cost of a workgroup), MI355X: one item alone over
+    # 1 / 2 / 4 rounds of workgroups (scripts/bench_wgrad.py calib), then fitted to 80 timed split plans of the three
+    # networks (`target` sweeps; profiles/r04_wgrad_splits.md: rms error 3 % for workgroups of <= 500 us)
+    CLASS_COST_US = {1.0: (8.4, 6.0), 0.6: (5.2, 6.0), 0.5: (4.1, 5.0), 0.3: (3.0, 8.0), 0.2: (2.2, 6.0),
+                     0.0: (1.45, 2.0)}
+    N_CU = 256
+    REDUCE_US_PER_MB = 0.54          # msdf_reduce_k reads the partial blocks at ~1.85 TB/s
 
     def splits(self, wx, wy):
         return self.split_fn(self.weight(wx, wy))
@@ -345,9 +355,14 @@ class WgradProgram:
     def rules_bytes(self):
         return np.frombuffer(b''.join(bytes(r) for r in self.rules), dtype=np.uint8).copy()
 
+    def wg_duration_us(self, it):
+        """Modelled duration of one workgroup of item `it` (all its splits are equally long up to one stage)."""
+        tau, t0 = self.CLASS_COST_US[it['weight']]
+        return t0 + tau * it.get('stages_per_wg', 1)
+
     def wg_map(self):
-        """int32 (item, split) pairs; long items first so the tail of the launch is made of short ones."""
-        order = sorted(range(len(self.items)), key=lambda i: -self.items[i]['weight'])
+        """int32 (item, split) pairs; long workgroups first so the tail of the launch is made of short ones."""
+        order = sorted(range(len(self.items)), key=lambda i: -self.wg_duration_us(self.items[i]))
         pairs = [(i, s) for i in order for s in range(self.items[i]['n_splits'])]
         return np.asarray(pairs, dtype=np.int32).reshape(-1)
 
@@ -368,15 +383,80 @@ class WgradProgram:
         return np.frombuffer(b''.join(out), dtype=np.uint8).copy()
 
 
-def balanced_program(build, mp, P_pad, target_points=1728):
-    """Split every item's point range into workgroups of about `target_points` points (54 stages of 32).
+def _makespan_us(durations, n_cu):
+    """In-order dispatch of workgroups (longest first) onto n_cu CUs that hold one workgroup each."""
+    import heapq
+    free = [0.0] * n_cu
+    for d in durations:
+        heapq.heapreplace(free, free[0] + d)
+    return max(free)
 
-    Measured on MI355X (scripts/bench_wgrad.py, profiles/README.md): many short workgroups (5 rounds over
-    the 256 CUs at P = 104,448: 61 splits x 21 items) beat one long workgroup per CU by 25 %, the optimum is
-    flat (+-3 % from 59 to 85 splits), and giving the narrow / column-sum-only items the same split count
-    keeps their latency-bound stages off the critical path."""
-    S = max(1, (P_pad + target_points - 1) // target_points)
-    return build(mp, P_pad, lambda w: S)
+
+_SPLIT_CACHE = {}
+
+
+def model_launch_us(prog):
+    """Modelled duration of a weight-gradient launch + its reduction (the objective of choose_splits)."""
+    durs = sorted((prog.wg_duration_us(it) for it in prog.items for _ in range(it['n_splits'])), reverse=True)
+    part = sum(it['n_splits'] * it['wx'] * max(it['wy'], 1) for it in prog.items)
+    return _makespan_us(durs, WgradProgram.N_CU), WgradProgram.REDUCE_US_PER_MB * 4e-6 * part
+
+
+def choose_splits(classes, n_stages, part_floats, target_us=None):
+    """Split count per item class for a launch of the given items.
+
+    classes: {class: number of items}, part_floats: {class: floats of partial sums one split of ALL items of the class
+    writes}.  The wide items are cut into workgroups of modelled duration D, every other class into workgroups of at
+    most D / 2 (short workgroups are what fills the end of the launch; they are dispatched last); D is the candidate
+    that minimises the modelled launch -- in-order dispatch, longest first, one workgroup per CU -- plus the time
+    msdf_reduce_k needs for the partial sums.  Round 3 used one split count for every item, sized for the 21 items of
+    the 8 x 256 network (61 splits: 5 rounds of workgroups); the 7 items of the network behind the hash grid then made
+    1.67 rounds."""
+    key = (tuple(sorted(classes.items())), n_stages, tuple(sorted(part_floats.items())), target_us)
+    if key in _SPLIT_CACHE:
+        return _SPLIT_CACHE[key]
+    cost = WgradProgram.CLASS_COST_US
+    top = max(classes)
+    best = None
+    # workgroups longer than ~500 us are outside what the model was fitted on (and measured 10-20 % slower than it says:
+    # the narrow classes are latency-bound when they run beside wide workgroups instead of beside each other)
+    for D in (np.geomspace(100.0, 500.0, 80) if target_us is None else [float(target_us)]):
+        S, part = {}, 0.0
+        for c, n_items in classes.items():
+            tau, t0 = cost[c]
+            d = D if c == top else 0.5 * D
+            S[c] = int(min(n_stages, max(1, math.ceil(n_stages * tau / max(d - t0, tau)))))
+            part += part_floats.get(c, 0) * S[c]
+        t = 0.0
+        for slow in (1.0, 1.3):        # the narrow classes as calibrated, and 30 % slower: pick what is good in both cases
+            durs = []
+            for c, n_items in classes.items():
+                tau, t0 = cost[c]
+                durs += [t0 + (tau if c == top else slow * tau) * -(-n_stages // S[c])] * (n_items * S[c])
+            durs.sort(reverse=True)
+            t = max(t, _makespan_us(durs, WgradProgram.N_CU))
+        t += WgradProgram.REDUCE_US_PER_MB * 4e-6 * part
+        if best is None or t < best[0] - 1e-9:
+            best = (t, S)
+    _SPLIT_CACHE[key] = best[1]
+    return best[1]
+
+
+def balanced_program(build, mp, P_pad, splits=None, target_us=None):
+    """The weight-gradient program of a network with its split counts chosen by choose_splits (or given per class;
+    target_us: the workgroup duration instead of the modelled optimum -- tuning runs)."""
+    if splits is None:
+        probe = build(mp, P_pad, lambda w: 1)
+        classes, part = {}, {}
+        for it in probe.items:
+            classes[it['weight']] = classes.get(it['weight'], 0) + 1
+            part[it['weight']] = part.get(it['weight'], 0) + it['wx'] * max(it['wy'], 1)
+        splits = choose_splits(classes, max(1, P_pad // 32), part, target_us)
+    prog = build(mp, P_pad, lambda w: splits[w])
+    n_stages = max(1, P_pad // 32)
+    for it in prog.items:
+        it['stages_per_wg'] = -(-n_stages // it['n_splits'])
+    return prog
 
 
 def _col_parts(L, in0_tiles):
