@@ -22,8 +22,8 @@ round) on the fp32 MFMA core, with `roofline` (dominant kernel, HIP-event timed 
 BASELINE.md section 3, rank 0, N=1 only).  Beside it, never mixed into `value` (N=1 only):
 `sharp_state` = the same step at density beta 0.01, where the sampler needs 2+ rounds, with the
 rounds per step and what the speculation of the round count cost; `hash_grid` = configs[2] with its HBM roofline;
-`alt_matrix_core` = the bf16x3 core, `alt_matrix_core_x6` = the bf16x6 core; `sustained` = 400 consecutive Adam steps from random init, a fresh ray batch
-every step (what training costs once beta moves and the sampler needs more rounds).
+`alt_matrix_core` = the bf16x3 core, `alt_matrix_core_x6` = the bf16x6 core; `sustained` = a 400-step TRAINING run (closed-form scene, fused
+MonoSDFLoss, Adam, fresh rays every step, density beta 0.02 at the start: beta falls and the sampler goes to 2+ rounds).
 """
 import argparse
 import json
@@ -42,7 +42,7 @@ sys.path.insert(0, ROOT)
 N_RAYS = 1024
 N_BATCHES = 8          # ray batches cycled through by the timed steps
 # entry points timed with HIP events inside the timed region (the kernels that make up >95 % of a step)
-TIMED = {'msdf_sdf_forward_if', 'msdf_sdf_fwd_grad', 'msdf_sdf_backward', 'msdf_wgrad', 'msdf_reduce',
+TIMED = {'msdf_sdf_forward_if', 'msdf_sdf_forward_lm', 'msdf_sdf_fwd_grad', 'msdf_sdf_backward', 'msdf_wgrad', 'msdf_reduce',
          'msdf_color_forward', 'msdf_color_backward', 'msdf_hash_encode_forward', 'msdf_hash_encode_backward',
          'msdf_hash_encode_second_backward', 'msdf_hash_encode_backward_ws', 'msdf_hash_encode_second_backward_ws',
          'msdf_hash_encode_backward_fused', 'msdf_hash_encode_backward_fused_out', 'msdf_hash_node_forward',
@@ -90,6 +90,44 @@ def probe_loss(out):
 def sdf_macs_per_point():
     """F_sdf = 39*256 + 2*256^2 + 256*217 + 4*256^2 + 256*257 = 524,544 MAC."""
     return 39 * 256 + 2 * 256 * 256 + 256 * 217 + 4 * 256 * 256 + 256 * 257
+
+
+def grid_sdf_macs_per_point():
+    """configs[2] (scannetGrids.conf:83-128): (39 PE + 32 grid features) x 256 + 256 x 256 + 256 x 257 = 149,504 MAC."""
+    return 71 * 256 + 256 * 256 + 256 * 257
+
+
+def scene_targets(rays, radius=0.6):
+    """Supervision of the `sustained` training run: a closed-form scene (the one the 200-step reference trajectories of
+    tests/golden/traj_*.npz were recorded on) -- rays from inside hit a sphere of `radius`; colour a smooth function of
+    the hit point, the depth cue the hit distance up to the monocular scale, the normal cue the inward normal in the
+    camera frame.  Shapes as the reference's data loader delivers them ([1, N, C]); computed on the device before
+    the timed region."""
+    o, d = rays['ray_cam_loc'].double(), rays['ray_dirs'].double()
+    b = (o * d).sum(-1)
+    c = (o * o).sum(-1) - radius * radius
+    t = -b + torch.sqrt(b * b - c)
+    p = o + t.unsqueeze(-1) * d
+    rgb = 0.5 + 0.4 * torch.sin(3.0 * p + torch.tensor([0.0, 1.0, 2.0], dtype=torch.float64, device=o.device))
+    rot = rays['ray_pose'][:, :3, :3].double().transpose(1, 2)
+    n_cam = (rot @ (-p / radius).unsqueeze(-1)).squeeze(-1)
+    depth = t * rays['ray_dirs_tmp'][:, 2].double().abs()
+    f = lambda a: a.float()[None].contiguous()
+    return {'rgb': f(rgb), 'depth': f((depth / 50.0).unsqueeze(-1)), 'normal': f(n_cam),
+            'mask': torch.ones(1, o.shape[0], 1, device=o.device)}
+
+
+def gather_ceiling(with_dy):
+    """Measured ceiling of the hash forward kernel's gathers (profiles/r04_gather_ceiling.json: scripts/dbg/
+    gather_ceiling.hip, mode "replay" -- the library's own index arithmetic on a training-like point set, the real table,
+    the real loads and stores, no interpolation arithmetic) in GB/s of SURVEY 8(d)'s algorithmic bytes, or None."""
+    path = os.path.join(ROOT, 'profiles', 'r04_gather_ceiling.json')
+    if not os.path.exists(path):
+        return None
+    for row in json.load(open(path)).get('rows', []):
+        if row.get('mode') == 'replay' and bool(row.get('dy_dx')) == bool(with_dy):
+            return row['GBps']
+    return None
 
 
 def _cpu_time(n_rays, iters, threads):
@@ -147,7 +185,8 @@ def pmc_traffic(entry, precision):
     # the bf16 kernels are templates on the number of planes: "void msdf_..._b16_k<2>" (bf16x3) / "<3>" (bf16x6)
     names = {'fp32': [base + '_k'], 'bf16x3': ['void %s_b16_k<2>' % base, base + '_b16_k'],
              'bf16x6': ['void %s_b16_k<3>' % base]}[precision]
-    for name in ('r03_pmc_%s.json' % precision, 'r02_pmc_%s.json' % precision, 'r01_v8_pmc_%s.json' % precision):
+    for name in ('r04_pmc_%s.json' % precision, 'r03_pmc_%s.json' % precision, 'r02_pmc_%s.json' % precision,
+                 'r01_v8_pmc_%s.json' % precision):
         path = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(path):
             table = json.load(open(path))
@@ -171,8 +210,9 @@ def pmc_traffic_grid(entry):
                'msdf_hash_node_input_gradient': ['void hg_node_input_gradient_kernel'],
                'msdf_hash_node_second_grad': ['void hg_node_second_grad_kernel'],
                'msdf_hash_node_scatter': ['void hb2_place_k', 'void hb2_accumulate_k']}
-    path = os.path.join(ROOT, 'profiles', 'r03_pmc_grid.json')
-    if not os.path.exists(path) or entry not in kernels:
+    path = next((os.path.join(ROOT, 'profiles', n) for n in ('r04_pmc_grid.json', 'r03_pmc_grid.json')
+                 if os.path.exists(os.path.join(ROOT, 'profiles', n))), None)
+    if path is None or entry not in kernels:
         return None, None
     table = json.load(open(path))
     tot = 0.0
@@ -181,10 +221,10 @@ def pmc_traffic_grid(entry):
         if row is None or 'hbm_bytes_per_launch_corrected' not in row:
             return None, None
         tot += row['hbm_bytes_per_launch_corrected']
-    return tot, 'profiles/r03_pmc_grid.json'
+    return tot, 'profiles/' + os.path.basename(path)
 
 
-def grid_report(args, kern, dt, world, rounds, loss, sampler):
+def grid_report(args, kern, dt, world, rounds, loss, sampler, backward_alone_ms=None):
     """configs[2]: roofline of the hash-grid entry points against HBM (SURVEY.md 8(d) bytes per point)."""
     P_main, P_smp = N_RAYS * 98 + 4 * N_RAYS, N_RAYS * 128
     # bytes per call of each entry point, summed over its launches in one step
@@ -213,6 +253,38 @@ def grid_report(args, kern, dt, world, rounds, loss, sampler):
         if n in kern:
             rows[n] = {'ms_per_step': kern[n]['ms_per_step'], 'algorithmic_GBps': b / (kern[n]['ms_per_step'] * 1e-3) / 1e9}
     dom = max(rows, key=lambda n: rows[n]['ms_per_step'])
+    # the hash forward kernel against its measured gather ceiling (per launch: the main pass has dy_dx, the sampler's not)
+    fwd = kern.get('msdf_hash_node_forward') or kern.get('msdf_hash_encode_forward')
+    ceiling = None
+    if fwd is not None and gather_ceiling(True) is not None:
+        n_l = fwd['launches_per_step']
+        ceil_ms = 1e-6 * (1548.0 * P_main / gather_ceiling(True) + 1164.0 * P_smp * max(0.0, n_l - 1.0) / gather_ceiling(False))
+        ceiling = {'kernel': 'hg_node_forward_kernel', 'ms_per_step': fwd['ms_per_step'], 'ceiling_ms_per_step': ceil_ms,
+                   'frac_of_gather_ceiling': ceil_ms / fwd['ms_per_step'],
+                   'ceiling_GBps': {'with_dy_dx': gather_ceiling(True), 'without': gather_ceiling(False)},
+                   'source': 'profiles/r04_gather_ceiling.json (scripts/dbg/gather_ceiling.hip, mode replay: the same index '
+                             'stream, loads and stores without the interpolation arithmetic)'}
+    # the MLP kernels own most of the configs[2] step: fraction of the fp32 MFMA peak of the dominant one and of the SDF
+    # weight-gradient launch (algorithmic FLOPs: 2 FLOP/MAC x the multipliers of SURVEY 8(d) on the 71-256-256-257 network)
+    Fg = grid_sdf_macs_per_point()
+    # (the sampler's no-grad forward needs the sdf row of the output layer only: 256 of its 256 x 257 MACs)
+    mlp_flops = {'msdf_sdf_forward_if': 2.0 * (Fg - 256 * 256) * P_smp, 'msdf_sdf_fwd_grad': 4.0 * Fg * P_main,
+                 'msdf_sdf_backward': 4.0 * Fg * P_main}
+    mlp = {}
+    for n, fl in mlp_flops.items():
+        if n in kern:
+            t = kern[n]['avg_ms'] * 1e-3
+            mlp[n] = {'avg_kernel_ms': kern[n]['avg_ms'], 'achieved': fl / t / 1e12, 'frac': fl / t / 1e12 / F32_MFMA_PEAK_TFLOPS}
+    mlp_dom = max(mlp, key=lambda n: mlp[n]['avg_kernel_ms']) if mlp else None
+    mlp_roofline = None
+    if mlp_dom is not None:
+        mlp_roofline = dict(mlp[mlp_dom], bound='mfma', kernel=mlp_dom, peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
+                            all_kernels={n: round(v['frac'], 3) for n, v in mlp.items()})
+        if mlp_dom == 'msdf_sdf_backward' and backward_alone_ms:
+            mlp_roofline['note'] = ('inside the step this kernel shares the chip with the colour network\'s weight-gradient '
+                                    'launch (second stream); `alone` = its own duration, 5 extra steps with that launch held back')
+            mlp_roofline['alone'] = {'avg_kernel_ms': backward_alone_ms,
+                                     'frac': mlp_flops[mlp_dom] / (backward_alone_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS}
     return {
         'metric': 'rays/sec fwd+bwd, 1024 rays x 98 samples, 16x2 hash grid + 2x256 SDF MLP',
         'value': world * N_RAYS * args.steps / dt, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
@@ -227,6 +299,8 @@ def grid_report(args, kern, dt, world, rounds, loss, sampler):
                      'note': 'parity of the hash-grid arithmetic is unpinned by reference outputs (CUDA-only in the '
                              'reference, no vectors): checked against the restated oracle only'},
         'hash_entry_points': rows,
+        'hash_forward_vs_gather_ceiling': ceiling,
+        'mlp_roofline': mlp_roofline,
         'kernels_ms_per_step': {k: round(v['ms_per_step'], 4) for k, v in sorted(kern.items())},
         'loss': loss,
     }
@@ -282,6 +356,68 @@ def launch_ranks(args, argv):
     return subprocess.call(cmd, env=env)
 
 
+RDZV_TIMEOUT_S = float(os.environ.get('MSDF_RDZV_TIMEOUT', '120'))
+
+
+class _RankPrefix:
+    """stderr of a rank with '[rank k] ' in front of every line (N ranks share the launcher's stderr)."""
+
+    def __init__(self, stream, rank):
+        self.stream, self.prefix, self.bol = stream, '[rank %d] ' % rank, True
+
+    def write(self, text):
+        for piece in text.splitlines(True):
+            if self.bol:
+                self.stream.write(self.prefix)
+            self.stream.write(piece)
+            self.bol = piece.endswith('\n')
+        return len(text)
+
+    def flush(self):
+        self.stream.flush()
+
+    def __getattr__(self, name):
+        return getattr(self.stream, name)
+
+
+def join_ranks(backend, rank, world, **pg_kwargs):
+    """Rendezvous that fails FAST and says who is missing (the reference's launch, training/exp_runner.py:73-77, waits
+    the default 10 minutes -- the driver's whole limit -- when a rank does not come up): every rank announces itself in
+    the store, then waits at most MSDF_RDZV_TIMEOUT (120 s) for the others; a rank that times out names the missing
+    ranks on stderr and the process exits non-zero.  Returns None on success, an exit code otherwise."""
+    import datetime
+    import torch.distributed as dist
+    timeout = datetime.timedelta(seconds=RDZV_TIMEOUT_S)
+    try:
+        if os.environ.get('TORCHELASTIC_USE_AGENT_STORE') == 'True':
+            # under torch.distributed.run the launcher's agent hosts the store: every rank is a client of it
+            store, _, _ = next(iter(dist.rendezvous('env://', rank, world, timeout=timeout)))
+        else:
+            # ranks started by hand: rank 0 hosts the store and does NOT wait for the others inside the constructor
+            # (that wait cannot say who is missing)
+            store = dist.TCPStore(os.environ['MASTER_ADDR'], int(os.environ['MASTER_PORT']), world, is_master=(rank == 0),
+                                  timeout=timeout, wait_for_workers=False)
+    except Exception as e:       # the store itself (hosted by rank 0 / the launcher) is not there
+        sys.stderr.write('bench.py: rank %d could not reach the rendezvous store at %s:%s within %g s (%s: %s) -- rank 0 / '
+                         'the launcher did not arrive\n' % (rank, os.environ.get('MASTER_ADDR'), os.environ.get('MASTER_PORT'),
+                                                            RDZV_TIMEOUT_S, type(e).__name__, e))
+        return 3
+    store.set_timeout(timeout)
+    store.set('bench/arrived/%d' % rank, '1')
+    t_end, missing = time.time() + RDZV_TIMEOUT_S, []
+    for r in range(world):
+        try:
+            store.wait(['bench/arrived/%d' % r], datetime.timedelta(seconds=max(0.05, t_end - time.time())))
+        except Exception:
+            missing.append(r)
+    if missing:
+        sys.stderr.write('bench.py: rank(s) %s of %d did not arrive within %g s -- giving up (exit 3)\n'
+                         % (', '.join(str(r) for r in missing), world, RDZV_TIMEOUT_S))
+        return 3
+    dist.init_process_group(backend=backend, store=store, rank=rank, world_size=world, timeout=timeout, **pg_kwargs)
+    return None
+
+
 class _StdoutToStderr:
     """RCCL / gloo may print a banner on stdout when the first communicator is built: stdout is kept for the one
     JSON line, so file descriptor 1 points at stderr while a process group comes up."""
@@ -302,7 +438,9 @@ def dry_run(args, rank, world):
     import torch.distributed as dist
     from monosdf_amd import parallel
     with _StdoutToStderr():
-        dist.init_process_group(backend='gloo', init_method='env://')
+        rc = join_ranks('gloo', rank, world)
+        if rc is not None:
+            return rc
         count = torch.ones(1)
         dist.all_reduce(count)
     try:
@@ -346,6 +484,8 @@ def main(argv=None):
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world > 1:
+        sys.stderr = _RankPrefix(sys.stderr, rank)
     if world != args.gpus:
         sys.stderr.write('bench.py: --gpus %d but the launcher started %d rank(s)\n' % (args.gpus, world))
         return 2
@@ -360,7 +500,9 @@ def main(argv=None):
     if use_dist:
         import torch.distributed as dist
         with _StdoutToStderr():
-            dist.init_process_group(backend='nccl', init_method='env://', device_id=device)
+            rc = join_ranks('nccl', rank, world, device_id=device)
+            if rc is not None:
+                return rc
             dist.barrier(device_ids=[local_rank])
             torch.cuda.synchronize()
 
@@ -379,10 +521,14 @@ def main(argv=None):
         pose = torch.eye(4, device=device).expand(n, 4, 4).contiguous()
         return {'ray_dirs': d, 'ray_cam_loc': o, 'ray_dirs_tmp': d.clone(), 'ray_pose': pose}
 
-    def measure(precision, grid=False, beta=0.1, steps=None, fresh=False):
+    def measure(precision, grid=False, beta=0.1, steps=None, fresh=False, train=False):
         """W warm-up + K timed steps of the training step on the given matrix core; returns the max over ranks.
-        fresh: a different ray batch EVERY step (pre-generated on the device) instead of cycling through 8."""
+        fresh: a different ray batch EVERY step (pre-generated on the device) instead of cycling through 8.
+        train: a training run instead of the probe loss -- targets of a closed-form scene (scene_targets), the fused
+        MonoSDFLoss with the weights of the reference's confs, NO warm-up steps (the run starts at the initial state);
+        the timed region is cut into windows of 100 steps (one host sync each)."""
         steps = args.steps if steps is None else steps
+        warmup = 0 if train else args.warmup
         torch.manual_seed(0)                      # same initial weights on every rank (as DDP would broadcast)
         model = MonoSDFNetwork(model_conf(grid=grid)).to(device).train()
         model.set_precision(precision)
@@ -396,10 +542,17 @@ def main(argv=None):
         averager = parallel.GradientAverager(params, timing=True) if use_dist else None
         torch.manual_seed(1234 + rank)            # per-rank sampling noise
         # every rank cycles through its own 8 batches (weak scaling: no DistributedSampler in the reference)
+        loss_fn, targets = None, None
         if fresh:
             gen = torch.Generator(device=device)
             gen.manual_seed(99 + rank)
-            batches = [device_rays(N_RAYS, gen) for _ in range(args.warmup + steps)]
+            batches = [device_rays(N_RAYS, gen) for _ in range(warmup + steps)]
+            if train:
+                from monosdf_amd.model.loss import MonoSDFLoss
+                # scannet_mlp.conf loss block: eikonal 0.05, smooth 0.005, depth 0.1, normal l1 / cos 0.05
+                loss_fn = MonoSDFLoss('torch.nn.L1Loss', eikonal_weight=0.05, smooth_weight=0.005, depth_weight=0.1,
+                                      normal_l1_weight=0.05, normal_cos_weight=0.05)
+                targets = [scene_targets(b) for b in batches]
         else:
             batches = [make_rays(N_RAYS, 1 + 1000 * rank + b, device) for b in range(N_BATCHES)]
         indices = torch.arange(N_RAYS, device=device)
@@ -409,7 +562,10 @@ def main(argv=None):
         def step(i):
             opt.zero_grad(set_to_none=True)
             out = model(batches[i % len(batches)], indices, if_pixel_input=True)
-            loss = ops.probe_loss(out)        # the BASELINE.md probe loss, value + gradients in one HIP launch
+            if loss_fn is not None:           # MonoSDFLoss (model/loss.py:252-311), value + gradients in one HIP launch
+                loss = loss_fn(out, targets[i % len(batches)], if_pixel_input=True)['loss']
+            else:
+                loss = ops.probe_loss(out)    # the BASELINE.md probe loss, value + gradients in one HIP launch
             loss.backward()
             if averager is not None:
                 averager.average()            # RCCL: the flat MLP block here, the table gradient already in flight
@@ -418,7 +574,7 @@ def main(argv=None):
             return loss
 
         first_loss = None
-        for i in range(args.warmup):
+        for i in range(warmup):
             l0 = step(i)
             first_loss = first_loss if first_loss is not None else float(l0.item())
         del rounds_seen[:]
@@ -429,11 +585,31 @@ def main(argv=None):
         _lib.PROFILE_NAMES = TIMED
         barrier()
         t0 = time.time()
+        windows = []
         for i in range(steps):
-            loss = step(args.warmup + i)
+            loss = step(warmup + i)
+            if train:
+                if first_loss is None:
+                    first_loss = loss           # read after the run (no sync inside the first step)
+                if (i + 1) % 100 == 0 or i + 1 == steps:
+                    torch.cuda.synchronize()
+                    windows.append((i + 1, time.time() - t0, float(model.density.get_beta().item())))
         barrier()
         dt_own = dt = time.time() - t0
         prof, _lib.PROFILE = _lib.PROFILE, None
+        if torch.is_tensor(first_loss):
+            first_loss = float(first_loss.item())
+        alone = None
+        if grid and world == 1:
+            # the backward kernel of the SDF network shares the chip with the colour network's weight-gradient launch
+            # (side stream) inside the step: its own duration, measured on 5 extra steps with that launch held back
+            early, ops.COLOR_WGRAD_EARLY = ops.COLOR_WGRAD_EARLY, False
+            _lib.PROFILE, _lib.PROFILE_NAMES = {}, {'msdf_sdf_backward'}
+            for i in range(5):
+                step(warmup + steps + i)
+            torch.cuda.synchronize()
+            alone = float(np.mean([a.elapsed_time(b) for a, b in _lib.PROFILE['msdf_sdf_backward']]))
+            _lib.PROFILE, _lib.PROFILE_NAMES, ops.COLOR_WGRAD_EARLY = None, TIMED, early
         multi = None
         if use_dist:
             t = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -458,6 +634,9 @@ def main(argv=None):
         kern = {}
         for name, evs in prof.items():
             ms = [a.elapsed_time(b) for a, b in evs]
+            # the sampler's SDF evaluations go through msdf_sdf_forward_lm (msdf_sdf_forward_if = the same without a
+            # level-major feature tensor): reported under the name the earlier rounds' lines use
+            name = 'msdf_sdf_forward_if' if name == 'msdf_sdf_forward_lm' else name
             kern[name] = {'launches_per_step': len(ms) / steps, 'avg_ms': float(np.mean(ms)),
                           'ms_per_step': float(np.sum(ms)) / steps}
         plan = model.implicit_network._fused(device).mp.plan
@@ -471,9 +650,12 @@ def main(argv=None):
                    # twice), `idle_rounds` = rounds enqueued beyond the ones that ran (one SDF evaluation of 131,072
                    # points each, results unused)
                    'repeated_passes': d['repeats'], 'idle_rounds': d['idle_rounds'], 'beta0': beta + 1e-4}
+        if averager is not None and not use_dist:
+            averager.close()
         return dict(dt=dt, dt_own=dt_own, steps=steps, kern=kern, rounds=hist, sampler=sampler, loss=float(loss.item()),
                     first_loss=first_loss, precision=precision, slots=(plan.hsum, plan.qsum, plan.absum), multi=multi,
-                    beta_end=float(model.density.get_beta().item()))
+                    beta_end=float(model.density.get_beta().item()), windows=windows, rounds_seq=list(rounds_seen),
+                    backward_alone_ms=alone)
 
     def mlp_rooflines(m):
         """Roofline of the dominant SDF kernel.  fp32 core: MFMA-bound (algorithmic FLOPs, SURVEY.md 8(d));
@@ -482,7 +664,9 @@ def main(argv=None):
         P_main, P_eik, P_smp = N_RAYS * 98, 4 * N_RAYS, N_RAYS * 128
         F = sdf_macs_per_point()
         flops = {   # algorithmic FLOPs per launch (2 FLOP / MAC), SURVEY.md 8(d) multipliers
-            'msdf_sdf_forward_if': 2.0 * F * P_smp,              # no-grad forward, 1 x F_sdf (skipped launches count too)
+            # no-grad forward of the sampler: get_sdf_vals needs the sdf ROW of the output layer only (256 of its
+            # 256 x 257 MACs) -- rounds 1-3 counted the whole layer here, as SURVEY's 1 x F_sdf does: 12.5 % too much
+            'msdf_sdf_forward_if': 2.0 * (F - 256 * 256) * P_smp,
             'msdf_sdf_fwd_grad': 2.0 * 2 * F * (P_main + P_eik),   # forward + d/dx sweep
             'msdf_sdf_backward': 2.0 * 2 * F * (P_main + P_eik),   # p-bar = W q-bar and h-bar = W^T a-bar sweeps
         }
@@ -522,7 +706,11 @@ def main(argv=None):
     alt6 = measure('bf16x6') if (extras and args.alt_precision and args.precision == 'fp32') else None
     # the hash-grid configuration: beside the headline at N = 1, and at N > 1 for its gradient exchange
     grid = measure('fp32', grid=True) if (extras or (use_dist and args.extras and not grid_only)) else None
-    sustained = measure(args.precision, steps=args.sustained_steps, fresh=True) \
+    # density beta at the start of the `sustained` training run: just above the value at which this random-init network's
+    # sampler starts to need a third round (all batches take 2 rounds at 0.014, 2-5 at 0.010), so that the falling beta
+    # of the run crosses it (from the confs' 0.1 a 400-step window would stay at one round)
+    SUSTAINED_BETA0 = 0.0125
+    sustained = measure(args.precision, beta=SUSTAINED_BETA0, steps=args.sustained_steps, fresh=True, train=True) \
         if (extras and args.sustained_steps > 0) else None
 
     if rank == 0:
@@ -530,7 +718,7 @@ def main(argv=None):
                  'bf16x6': 'bf16x6 (fp32 split into 3 bf16, 6 products, fp32 accumulate)'}[args.precision]
         if grid_only:
             res = grid_report(args, primary['kern'], primary['dt'], world, primary['sampler']['mean_rounds'],
-                              primary['loss'], primary['sampler'])
+                              primary['loss'], primary['sampler'], primary['backward_alone_ms'])
             res['dtype'] = dtype
             if primary['multi'] is not None:
                 res['multi_gpu'] = primary['multi']
@@ -556,7 +744,10 @@ def main(argv=None):
             'loss': primary['loss'],
         }
         if primary['multi'] is not None:
-            res['multi_gpu'] = dict(primary['multi'], backend='nccl (RCCL)')
+            res['multi_gpu'] = dict(primary['multi'], backend='nccl (RCCL)',
+                                    note='the overlap of the hash-grid table all-reduce with the weight-gradient kernels is '
+                                         'a design until a SCALE record of this line exists: `allreduce_ms_per_step` is '
+                                         'the time between HIP events around each message, not its exposed part')
             if grid is not None:
                 res['multi_gpu']['hash_grid'] = dict(grid['multi'], value=rate(grid), unit='rays/s',
                                                      ms_per_step=1e3 * grid['dt'] / grid['steps'])
@@ -569,21 +760,35 @@ def main(argv=None):
                 'sampler': sharp['sampler'], 'roofline': smf if args.precision == 'fp32' else (shb or smf),
                 'kernels_ms_per_step': ms(sharp)}
         if sustained is not None:
+            wins, prev_n, prev_t = [], 0, 0.0
+            seq = sustained['rounds_seq']
+            for n, t, b in sustained['windows']:
+                wins.append({'steps': '%d-%d' % (prev_n + 1, n), 'ms_per_step': 1e3 * (t - prev_t) / (n - prev_n),
+                             'mean_rounds': float(np.mean(seq[prev_n:n])), 'beta_at_end': b})
+                prev_n, prev_t = n, t
             res['sustained'] = {
-                'what': '%d consecutive training steps (fwd + loss + bwd + Adam, lr 5e-4) from the random-init state, a '
-                        'FRESH ray batch every step: density beta moves, the sampler starts to need 2+ rounds, the '
-                        'round-count guess misses now and then' % sustained['steps'],
+                'what': 'a TRAINING run of %d consecutive steps on the configs[1] network: forward + fused MonoSDFLoss '
+                        '(weights of scannet_mlp.conf) against the targets of a closed-form scene (a sphere seen from '
+                        'inside, the scene of tests/golden/traj_*.npz) + backward + Adam (lr 5e-4), a FRESH ray batch every '
+                        'step, from the random-init weights with density beta = %g (just above where this network\'s sampler starts '
+                        'to need a third round; the reference\'s confs start at 0.1 and reach such values after tens of '
+                        'thousands of steps): beta falls, the rounds per step go up, the round-count guess misses now and '
+                        'then.  No warm-up: the first window contains the first step' % (
+                            sustained['steps'], SUSTAINED_BETA0),
                 'value': rate(sustained), 'unit': 'rays/s', 'steps': sustained['steps'],
                 'ms_per_step': 1e3 * sustained['dt'] / sustained['steps'],
-                'seconds': sustained['dt'], 'sampler': sustained['sampler'],
-                'beta_start': args.beta + 1e-4, 'beta_end': sustained['beta_end'],
+                'ms_per_step_first_100': wins[0]['ms_per_step'] if wins else None,
+                'ms_per_step_last_100': wins[-1]['ms_per_step'] if wins else None,
+                'windows': wins, 'seconds': sustained['dt'], 'sampler': sustained['sampler'],
+                'beta_start': SUSTAINED_BETA0 + 1e-4, 'beta_end': sustained['beta_end'],
                 'loss_first_step': sustained['first_loss'], 'loss_last_step': sustained['loss'],
                 'kernels_ms_per_step': ms(sustained)}
         if grid is not None and single:
             g = grid_report(args, grid['kern'], grid['dt'], world, grid['sampler']['mean_rounds'], grid['loss'],
-                            grid['sampler'])
+                            grid['sampler'], grid['backward_alone_ms'])
             res['hash_grid'] = {k: g[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'config', 'roofline',
-                                                  'hash_entry_points', 'kernels_ms_per_step')}
+                                                  'mlp_roofline', 'hash_forward_vs_gather_ceiling', 'hash_entry_points',
+                                                  'kernels_ms_per_step')}
         if alt is not None:
             amf, ahb = mlp_rooflines(alt)
             other = 'bf16x3' if args.precision == 'fp32' else 'fp32'

@@ -49,7 +49,7 @@ extern "C" {
 #define MSDF_ERR_LAUNCH 2
 #define MSDF_ERR_UNSUPPORTED 3
 
-#define MSDF_ABI_VERSION 7
+#define MSDF_ABI_VERSION 8
 int msdf_abi_version(void);
 
 /* ---- hash grid (reference: hashencoder/src/hashencoder.h:13-15) ----
@@ -160,6 +160,11 @@ int msdf_sdf_forward(const msdf_plan_t* plan, const void* wpack, const float* bp
 int msdf_sdf_forward_if(const msdf_plan_t* plan, const void* wpack, const float* bpack, const float* x,
                         const float* aux, int P, float clamp_radius, float sphere_scale, float* sdf,
                         const uint32_t* run_flag, void* stream);
+/* the same with the extra input features given as the hash encoder's level-major tensor [aux_LC / aux_C][P][aux_C]
+ * (msdf_fg_args_t.aux_C); aux_C == 0 is msdf_sdf_forward_if */
+int msdf_sdf_forward_lm(const msdf_plan_t* plan, const void* wpack, const float* bpack, const float* x,
+                        const float* aux, int aux_C, int aux_LC, int P, float clamp_radius, float sphere_scale,
+                        float* sdf, const uint32_t* run_flag, void* stream);
 
 typedef struct {
   const void* wpack;
@@ -179,6 +184,9 @@ typedef struct {
   float* PM;               /* [hsum * P_pad] */
   float* IN0;              /* [P_pad, 16*(e_tiles+aux_tiles)] */
   int32_t save;
+  int32_t aux_C;           /* layout of aux / r_aux: 0 = rows [P, 16*aux_tiles]; C = 1, 2, 4, 8: the hash encoder's own
+                              level-major tensors [aux_LC / C][P][C] (column l C + c of a point = level l, channel c) */
+  int32_t aux_LC;          /* valid columns (levels x channels) of the level-major form */
   int32_t pad_;
 } msdf_fg_args_t;
 int msdf_sdf_fwd_grad(const msdf_plan_t* plan, const msdf_fg_args_t* args, void* stream);
@@ -208,6 +216,7 @@ typedef struct {
   float* g_aux;            /* [P, 16*aux_tiles] or NULL */
   const float* g_sdf_b;    /* [P - n_split] or NULL */
   const float* g_nrm_b;    /* [P - n_split, 3] or NULL */
+  int32_t aux_C, aux_LC;   /* layout of g_raux / g_aux, as in msdf_fg_args_t */
 } msdf_bw_args_t;
 int msdf_sdf_backward(const msdf_plan_t* plan, const msdf_bw_args_t* args, void* stream);
 

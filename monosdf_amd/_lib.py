@@ -54,7 +54,8 @@ class FgArgs(C.Structure):
                 ('P', C.c_int32), ('P_pad', C.c_int32), ('n_clamp', C.c_int32), ('n_feat', C.c_int32),
                 ('clamp_radius', C.c_float), ('sphere_scale', C.c_float),
                 ('sdf', _P), ('feat', _P), ('nrm', _P), ('r_aux', _P), ('clamped', _P),
-                ('H', _P), ('PM', _P), ('IN0', _P), ('save', C.c_int32), ('pad_', C.c_int32)]
+                ('H', _P), ('PM', _P), ('IN0', _P), ('save', C.c_int32), ('aux_C', C.c_int32), ('aux_LC', C.c_int32),
+                ('pad_', C.c_int32)]
 
 
 class BwArgs(C.Structure):
@@ -62,7 +63,7 @@ class BwArgs(C.Structure):
                 ('P', C.c_int32), ('P_pad', C.c_int32), ('n_feat', C.c_int32), ('n_split', C.c_int32),
                 ('g_sdf', _P), ('g_feat', _P), ('g_nrm', _P), ('g_raux', _P), ('clamped', _P),
                 ('H', _P), ('PM', _P), ('QB', _P), ('T', _P), ('AB', _P), ('GSDF', _P), ('QLAST', _P),
-                ('g_aux', _P), ('g_sdf_b', _P), ('g_nrm_b', _P)]
+                ('g_aux', _P), ('g_sdf_b', _P), ('g_nrm_b', _P), ('aux_C', C.c_int32), ('aux_LC', C.c_int32)]
 
 
 class ColorFwdArgs(C.Structure):
@@ -163,6 +164,7 @@ _SIGNATURES = {
     'msdf_pack_weights': [C.POINTER(Plan), _P, _P, _P, _P, _P, _P, _P],
     'msdf_sdf_forward': [C.POINTER(Plan), _P, _P, _P, _P, C.c_int, C.c_float, C.c_float, _P, _P],
     'msdf_sdf_forward_if': [C.POINTER(Plan), _P, _P, _P, _P, C.c_int, C.c_float, C.c_float, _P, _P, _P],
+    'msdf_sdf_forward_lm': [C.POINTER(Plan), _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P, _P, _P],
     'msdf_sdf_fwd_grad': [C.POINTER(Plan), C.POINTER(FgArgs), _P],
     'msdf_sdf_backward': [C.POINTER(Plan), C.POINTER(BwArgs), _P],
     'msdf_color_forward': [C.POINTER(Plan), C.POINTER(ColorFwdArgs), _P],
@@ -185,7 +187,7 @@ _SIGNATURES = {
     'msdf_laplace_density_backward': [_P, _P, C.c_int, C.c_int64, C.c_int, _P, _P, _P, _P],
 }
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _lib = None
 

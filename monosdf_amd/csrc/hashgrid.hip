@@ -1333,9 +1333,9 @@ hg_transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, cons
 
 extern "C" int msdf_hash_transpose(const float* src, float* dst, const float* src2, float* dst2, uint32_t L,
                                    uint32_t B, uint32_t C, uint32_t pitch, int to_point_major, void* stream) {
+  if (B == 0) return MSDF_OK;          // an empty point set has NULL tensors (empty CUDA tensors have no storage)
   if (src == nullptr || dst == nullptr || (src2 == nullptr) != (dst2 == nullptr) || pitch < L * C || L * C == 0)
     return MSDF_ERR_ARG;
-  if (B == 0) return MSDF_OK;
   const size_t lds = (size_t)HT_PTS * (L * C + 1) * sizeof(float);
   if (lds > 64 * 1024) return MSDF_ERR_UNSUPPORTED;
   const dim3 grid((B + HT_PTS - 1) / HT_PTS, src2 != nullptr ? 2 : 1);
@@ -1348,8 +1348,8 @@ extern "C" int msdf_hash_transpose(const float* src, float* dst, const float* sr
 extern "C" int msdf_hash_node_forward(const float* x, double divide_factor, float* x01_out, const float* embeddings,
                                       const int* offsets, float* feat, uint32_t pitch, uint32_t B, uint32_t C,
                                       uint32_t L, float S, uint32_t H, float* dy_dx, void* stream) {
+  if (B == 0) return MSDF_OK;          // as msdf_hash_encode_forward: nothing to do, NULL tensors allowed
   if ((pitch != 0 && pitch < L * C) || x == nullptr || feat == nullptr) return MSDF_ERR_ARG;
-  if (B == 0) return MSDF_OK;
   // what the module's `x / divide_factor` multiplies by on the device: the reciprocal formed in double, rounded to
   // fp32 (scripts/dbg/x01_rounding.py: bit-identical on 196,608 values; 1.0f / 1.1f differs in 41 % of them)
   const float inv = (float)(1.0 / divide_factor);
@@ -1361,8 +1361,8 @@ extern "C" int msdf_hash_node_forward(const float* x, double divide_factor, floa
 
 extern "C" int msdf_hash_node_input_gradient(const float* g, uint32_t pitch, const float* dy_dx, uint32_t B,
                                              uint32_t C, uint32_t L, float scale, float* inout, void* stream) {
-  if ((pitch != 0 && pitch < L * C) || g == nullptr || dy_dx == nullptr || inout == nullptr) return MSDF_ERR_ARG;
   if (B == 0) return MSDF_OK;
+  if ((pitch != 0 && pitch < L * C) || g == nullptr || dy_dx == nullptr || inout == nullptr) return MSDF_ERR_ARG;
   if ((uint64_t)B * 3 >= (1ull << 32)) return MSDF_ERR_UNSUPPORTED;
   HG_DISPATCH_C(C, (hg_node_input_gradient_kernel<CC><<<(3 * B + HG_THREADS - 1) / HG_THREADS, HG_THREADS, 0,
                                                         (hipStream_t)stream>>>(g, pitch, dy_dx, B, L, scale, inout)));
@@ -1372,9 +1372,9 @@ extern "C" int msdf_hash_node_input_gradient(const float* g, uint32_t pitch, con
 extern "C" int msdf_hash_node_second_grad(const float* g_a, const float* g_b, uint32_t n_split, float scale,
                                           float* gg_out, const float* dy_dx, float* grad_grad, uint32_t pitch,
                                           uint32_t B, uint32_t C, uint32_t L, void* stream) {
+  if (B == 0) return MSDF_OK;
   if ((pitch != 0 && pitch < L * C) || gg_out == nullptr || dy_dx == nullptr || grad_grad == nullptr || n_split > B)
     return MSDF_ERR_ARG;
-  if (B == 0) return MSDF_OK;
   const dim3 grid((B + HG_THREADS - 1) / HG_THREADS, L);
   HG_DISPATCH_C(C, (hg_node_second_grad_kernel<CC><<<grid, HG_THREADS, 0, (hipStream_t)stream>>>(
                        g_a, g_b, n_split, scale, gg_out, dy_dx, grad_grad, pitch, B, L)));
@@ -1387,13 +1387,15 @@ extern "C" int msdf_hash_node_scatter(const float* grad_first, const float* grad
                                       uint32_t C, uint32_t L, float S, uint32_t H, const float* grad_grad_inputs,
                                       uint64_t n_entries, void* workspace, uint64_t workspace_bytes, void* stream) {
   if (C == 1) return MSDF_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0) {                        // no points: the table gradient is all zeros (the other tensors may be NULL)
+    if (grad_embeddings == nullptr) return MSDF_ERR_ARG;
+    return hipMemsetAsync(grad_embeddings, 0, (size_t)n_entries * C * sizeof(float), st) == hipSuccess ? MSDF_OK
+                                                                                                      : MSDF_ERR_LAUNCH;
+  }
   if ((pitch != 0 && pitch < L * C) || grad_embeddings == nullptr || grad_first == nullptr || grad_second == nullptr ||
       grad_grad_inputs == nullptr)
     return MSDF_ERR_ARG;
-  hipStream_t st = (hipStream_t)stream;
-  if (B == 0)
-    return hipMemsetAsync(grad_embeddings, 0, (size_t)n_entries * C * sizeof(float), st) == hipSuccess ? MSDF_OK
-                                                                                                      : MSDF_ERR_LAUNCH;
   HG_DISPATCH_C(C, {
     const int rc = hb_run<CC, 2>(grad_first, grad_second, inputs, offsets, grad_grad_inputs, grad_embeddings, B, L, S,
                                  H, n_entries, workspace, workspace_bytes, st, true, pitch);

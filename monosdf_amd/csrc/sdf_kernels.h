@@ -29,16 +29,50 @@ __device__ __forceinline__ PointCtx load_point(const float* __restrict__ x, cons
   return c;
 }
 
-// network input tiles: PE tiles then aux tiles (hash-grid features, [P x 16*aux_tiles] row-major)
+// Extra input features of a point (hash-grid features) and everything shaped like them (d sdf / d features, their
+// gradients): either rows [P, 16 * aux_tiles] (C == 0) or the hash encoder's own level-major tensor [L][P][C] with
+// L C = LC valid columns (C = 2: what every configuration of the reference uses; other channel counts take the rows),
+// column l C + c of a point = level l, channel c.  A lane owns the columns 16 t + 4 q + r of its point: two levels per
+// tile, two 8-byte pieces, 128 contiguous bytes per level over the 16 points of a wave.  Reading and writing the level-major tensors
+// here is what removes the three transposes around the encoder and the scatter from the training step.
+struct AuxView {
+  int C, LC, P;
+};
+typedef float v2f_aux __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v4f aux_load_tile(const float* __restrict__ base, const AuxView av, const int aux_tiles,
+                                             const int t, const int pt, const int q) {
+  const int s0 = 16 * t + 4 * q;
+  if (av.C == 0) return *(const v4f*)(base + (size_t)pt * (16 * aux_tiles) + s0);
+  // C == 2: levels s0 / 2 and s0 / 2 + 1 (LC is even: both inside or both outside)
+  const int l = (s0 < av.LC) ? (s0 >> 1) : 0;
+  const v2f_aux a = *(const v2f_aux*)(base + ((size_t)l * av.P + pt) * 2);
+  const v2f_aux b = *(const v2f_aux*)(base + ((size_t)(l + (s0 + 2 < av.LC ? 1 : 0)) * av.P + pt) * 2);
+  v4f v = (v4f){a.x, a.y, b.x, b.y};
+  if (s0 >= av.LC) v = V4ZERO;
+  else if (s0 + 2 >= av.LC) { v.z = 0.f; v.w = 0.f; }
+  return v;
+}
+
+__device__ __forceinline__ void aux_store_tile(float* __restrict__ base, const AuxView av, const int aux_tiles,
+                                               const int t, const int pt, const int q, const v4f v) {
+  const int s0 = 16 * t + 4 * q;
+  if (av.C == 0) { *(v4f*)(base + (size_t)pt * (16 * aux_tiles) + s0) = v; return; }
+  if (s0 >= av.LC) return;
+  const int l = s0 >> 1;
+  *(v2f_aux*)(base + ((size_t)l * av.P + pt) * 2) = (v2f_aux){v.x, v.y};
+  if (s0 + 2 < av.LC) *(v2f_aux*)(base + ((size_t)(l + 1) * av.P + pt) * 2) = (v2f_aux){v.z, v.w};
+}
+
+// network input tiles: PE tiles then aux tiles (hash-grid features)
 __device__ __forceinline__ void load_input_tiles(v4f (&in0)[5], const msdf_plan_t& plan,
-                                                 const float* __restrict__ aux, const PointCtx& c) {
+                                                 const float* __restrict__ aux, const AuxView av, const PointCtx& c) {
   pe_values(in0, c.x0, c.x1, c.x2, plan.n_freqs);
   in0[3] = in0[4] = V4ZERO;
   if (plan.aux_tiles > 0) {
-    const int aw = 16 * plan.aux_tiles;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
-      if (t < plan.aux_tiles) in0[3 + t] = *(const v4f*)(aux + (size_t)c.ptc * aw + 16 * t + 4 * c.q);
+      if (t < plan.aux_tiles) in0[3 + t] = aux_load_tile(aux, av, plan.aux_tiles, t, c.ptc, c.q);
   }
 }
 
@@ -219,14 +253,15 @@ struct SweepDownHooks {
 template <class Core>
 __device__ __forceinline__ void sdf_forward_body(const msdf_plan_t& plan, const typename Core::wvec* __restrict__ wpack,
                                                  const float* __restrict__ bpack, const float* __restrict__ x,
-                                                 const float* __restrict__ aux, const int P, const float clamp_radius,
-                                                 const float sphere_scale, float* __restrict__ sdf_out, void* lds) {
+                                                 const float* __restrict__ aux, const AuxView av, const int P,
+                                                 const float clamp_radius, const float sphere_scale,
+                                                 float* __restrict__ sdf_out, void* lds) {
   const PointCtx c = load_point(x, P);
   v4f in[MT], acc[MT];
   const int in0_tiles = plan.e_tiles + plan.aux_tiles;
   {
     v4f in0[5];
-    load_input_tiles(in0, plan, aux, c);
+    load_input_tiles(in0, plan, aux, av, c);
     place_tiles(in, 0, in0, in0_tiles);
   }
   const int nl = plan.n_layers;
@@ -235,7 +270,7 @@ __device__ __forceinline__ void sdf_forward_body(const msdf_plan_t& plan, const 
     // skip layer: the network input is appended after the hidden tiles (1/sqrt2 folded into the pack)
     if (L.skip_tile >= 0) {
       v4f in0[5];
-      load_input_tiles(in0, plan, aux, c);
+      load_input_tiles(in0, plan, aux, av, c);
       place_tiles(in, L.skip_tile, in0, in0_tiles);
     }
     if constexpr (Core::BIAS_IN_HOOKS) {
@@ -265,13 +300,14 @@ template <class Core>
 __device__ __forceinline__ void sdf_fwd_grad_body(const msdf_plan_t& plan, const FgArgs& a, void* lds) {
   typedef typename Core::wvec wvec;
   const PointCtx c = load_point(a.x, a.P);
+  const AuxView av = {a.aux_C, a.aux_LC, a.P};
   v4f in[MT], acc[MT];
   const int nl = plan.n_layers;
   const int in0_tiles = plan.e_tiles + plan.aux_tiles;
   const size_t Pp = (size_t)a.P_pad;
   {
     v4f in0[5];
-    load_input_tiles(in0, plan, a.aux, c);
+    load_input_tiles(in0, plan, a.aux, av, c);
     place_tiles(in, 0, in0, in0_tiles);
     if (a.save) {
 #pragma unroll
@@ -287,7 +323,7 @@ __device__ __forceinline__ void sdf_fwd_grad_body(const msdf_plan_t& plan, const
     const msdf_layer_t L = plan.layer[l];
     if (L.skip_tile >= 0) {
       v4f in0[5];
-      load_input_tiles(in0, plan, a.aux, c);
+      load_input_tiles(in0, plan, a.aux, av, c);
       place_tiles(in, L.skip_tile, in0, in0_tiles);
     }
     float* Hl = a.H + (size_t)L.hpre * Pp + (size_t)c.pt * (16 * L.ot) + 4 * c.q;
@@ -402,13 +438,12 @@ __device__ __forceinline__ void sdf_fwd_grad_body(const msdf_plan_t& plan, const
       a.clamped[c.pt] = is_clamped ? 1 : 0;
     }
     if (a.r_aux != nullptr) {
-      const int aw = 16 * plan.aux_tiles;
 #pragma unroll
       for (int t = 0; t < 2; ++t)
         if (t < plan.aux_tiles) {
           v4f v = r_aux[t];
           if (is_clamped) v = V4ZERO;
-          *(v4f*)(a.r_aux + (size_t)c.pt * aw + 16 * t + 4 * c.q) = v;
+          aux_store_tile(a.r_aux, av, plan.aux_tiles, t, c.pt, c.q, v);
         }
     }
   }
@@ -428,10 +463,10 @@ __device__ __forceinline__ void load_rbar(v4f (&rbar)[5], const msdf_plan_t& pla
   pe_jacobian(rbar, c.x0, c.x1, c.x2, plan.n_freqs, gn0, gn1, gn2);
   rbar[3] = rbar[4] = V4ZERO;
   if (a.g_raux != nullptr && live) {
-    const int aw = 16 * plan.aux_tiles;
+    const AuxView av = {a.aux_C, a.aux_LC, a.P};
 #pragma unroll
     for (int t = 0; t < 2; ++t)
-      if (t < plan.aux_tiles) rbar[3 + t] = *(const v4f*)(a.g_raux + (size_t)c.pt * aw + 16 * t + 4 * c.q);
+      if (t < plan.aux_tiles) rbar[3 + t] = aux_load_tile(a.g_raux, av, plan.aux_tiles, t, c.pt, c.q);
   }
 }
 
@@ -546,10 +581,10 @@ __device__ __forceinline__ void sdf_backward_body(const msdf_plan_t& plan, const
     }
   }
   if (a.g_aux != nullptr && c.valid) {
-    const int aw = 16 * plan.aux_tiles;
+    const AuxView av = {a.aux_C, a.aux_LC, a.P};
 #pragma unroll
     for (int t = 0; t < 2; ++t)
-      if (t < plan.aux_tiles) *(v4f*)(a.g_aux + (size_t)c.pt * aw + 16 * t + 4 * c.q) = g_in_aux[t];
+      if (t < plan.aux_tiles) aux_store_tile(a.g_aux, av, plan.aux_tiles, t, c.pt, c.q, g_in_aux[t]);
   }
 }
 

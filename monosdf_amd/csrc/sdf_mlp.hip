@@ -80,12 +80,12 @@ __global__ void __launch_bounds__(256) msdf_pack_kernel(const msdf_plan_t plan,
 
 __global__ void __launch_bounds__(MLP_THREADS, MLP_WGS_PER_CU)
 msdf_sdf_forward_k(const msdf_plan_t plan, const v4f* __restrict__ wpack, const float* __restrict__ bpack,
-                   const float* __restrict__ x, const float* __restrict__ aux, const int P,
+                   const float* __restrict__ x, const float* __restrict__ aux, const AuxView av, const int P,
                    const float clamp_radius, const float sphere_scale, float* __restrict__ sdf_out,
                    const uint32_t* __restrict__ run_flag) {
   extern __shared__ v4f lds[];
   if (run_flag != nullptr && *run_flag == 0u) return;     // a sampler round nobody asked for (uniform over the grid)
-  sdf_forward_body<CoreF32>(plan, wpack, bpack, x, aux, P, clamp_radius, sphere_scale, sdf_out, lds);
+  sdf_forward_body<CoreF32>(plan, wpack, bpack, x, aux, av, P, clamp_radius, sphere_scale, sdf_out, lds);
 }
 
 __global__ void __launch_bounds__(MLP_THREADS, MLP_WGS_PER_CU)
@@ -103,8 +103,8 @@ msdf_sdf_backward_k(const msdf_plan_t plan, const BwArgs a) {
 // bf16x3 launchers (sdf_mlp_b16.hip)
 int msdf_b16_pack_weights(const msdf_plan_t*, const msdf_packrule_t*, const int*, const float*, const float*, void*,
                           float*, hipStream_t);
-int msdf_b16_sdf_forward(const msdf_plan_t*, const void*, const float*, const float*, const float*, int, float, float,
-                         float*, const uint32_t*, hipStream_t);
+int msdf_b16_sdf_forward(const msdf_plan_t*, const void*, const float*, const float*, const float*, int, int, int, float,
+                         float, float*, const uint32_t*, hipStream_t);
 int msdf_b16_sdf_fwd_grad(const msdf_plan_t*, const msdf_fg_args_t*, hipStream_t);
 int msdf_b16_sdf_backward(const msdf_plan_t*, const msdf_bw_args_t*, hipStream_t);
 
@@ -123,20 +123,34 @@ extern "C" int msdf_pack_weights(const msdf_plan_t* plan, const msdf_packrule_t*
   return msdf_check_launch();
 }
 
-extern "C" int msdf_sdf_forward_if(const msdf_plan_t* plan, const void* wpack, const float* bpack, const float* x,
-                                   const float* aux, int P, float clamp_radius, float sphere_scale, float* sdf,
-                                   const uint32_t* run_flag, void* stream) {
+static bool aux_layout_ok(const msdf_plan_t* plan, const int aux_C, const int aux_LC) {
+  if (aux_C == 0) return true;
+  return aux_C == 2 && aux_LC > 0 && (aux_LC % aux_C) == 0 &&
+         aux_LC <= 16 * plan->aux_tiles;
+}
+
+extern "C" int msdf_sdf_forward_lm(const msdf_plan_t* plan, const void* wpack, const float* bpack, const float* x,
+                                   const float* aux, int aux_C, int aux_LC, int P, float clamp_radius,
+                                   float sphere_scale, float* sdf, const uint32_t* run_flag, void* stream) {
   if (plan == nullptr || P < 0) return MSDF_ERR_ARG;
   if (P == 0) return MSDF_OK;
   if (plan->aux_tiles > 0 && aux == nullptr) return MSDF_ERR_ARG;
+  if (!aux_layout_ok(plan, aux_C, aux_LC)) return MSDF_ERR_ARG;
   if (plan->precision == MSDF_PRECISION_BF16X3 || plan->precision == MSDF_PRECISION_BF16X6)
-    return msdf_b16_sdf_forward(plan, wpack, bpack, x, aux, P, clamp_radius, sphere_scale, sdf, run_flag,
+    return msdf_b16_sdf_forward(plan, wpack, bpack, x, aux, aux_C, aux_LC, P, clamp_radius, sphere_scale, sdf, run_flag,
                                 (hipStream_t)stream);
   if (mlp_prepare((const void*)msdf_sdf_forward_k)) return MSDF_ERR_LAUNCH;
   const int grid = (P + MLP_PTS_PER_WG - 1) / MLP_PTS_PER_WG;
+  const AuxView av = {aux_C, aux_LC, P};
   msdf_sdf_forward_k<<<grid, MLP_THREADS, MLP_LDS_BYTES, (hipStream_t)stream>>>(
-      *plan, (const v4f*)wpack, bpack, x, aux, P, clamp_radius, sphere_scale, sdf, run_flag);
+      *plan, (const v4f*)wpack, bpack, x, aux, av, P, clamp_radius, sphere_scale, sdf, run_flag);
   return msdf_check_launch();
+}
+
+extern "C" int msdf_sdf_forward_if(const msdf_plan_t* plan, const void* wpack, const float* bpack, const float* x,
+                                   const float* aux, int P, float clamp_radius, float sphere_scale, float* sdf,
+                                   const uint32_t* run_flag, void* stream) {
+  return msdf_sdf_forward_lm(plan, wpack, bpack, x, aux, 0, 0, P, clamp_radius, sphere_scale, sdf, run_flag, stream);
 }
 
 extern "C" int msdf_sdf_forward(const msdf_plan_t* plan, const void* wpack, const float* bpack, const float* x,
@@ -150,6 +164,7 @@ extern "C" int msdf_sdf_fwd_grad(const msdf_plan_t* plan, const msdf_fg_args_t* 
   if (a->P == 0) return MSDF_OK;
   if (a->P_pad < a->P || (a->P_pad % MLP_PTS_PER_WG) != 0) return MSDF_ERR_ARG;
   if (plan->aux_tiles > 0 && a->aux == nullptr) return MSDF_ERR_ARG;
+  if (!aux_layout_ok(plan, a->aux_C, a->aux_LC)) return MSDF_ERR_ARG;
   if (plan->precision == MSDF_PRECISION_BF16X3 || plan->precision == MSDF_PRECISION_BF16X6) return msdf_b16_sdf_fwd_grad(plan, a, (hipStream_t)stream);
   if (mlp_prepare((const void*)msdf_sdf_fwd_grad_k)) return MSDF_ERR_LAUNCH;
   msdf_sdf_fwd_grad_k<<<a->P_pad / MLP_PTS_PER_WG, MLP_THREADS, MLP_LDS_BYTES, (hipStream_t)stream>>>(*plan, *a);
@@ -160,6 +175,7 @@ extern "C" int msdf_sdf_backward(const msdf_plan_t* plan, const msdf_bw_args_t* 
   if (plan == nullptr || a == nullptr || a->P < 0) return MSDF_ERR_ARG;
   if (a->P == 0) return MSDF_OK;
   if (a->P_pad < a->P || (a->P_pad % MLP_PTS_PER_WG) != 0) return MSDF_ERR_ARG;
+  if (!aux_layout_ok(plan, a->aux_C, a->aux_LC)) return MSDF_ERR_ARG;
   if (plan->precision == MSDF_PRECISION_BF16X3 || plan->precision == MSDF_PRECISION_BF16X6) return msdf_b16_sdf_backward(plan, a, (hipStream_t)stream);
   if (mlp_prepare((const void*)msdf_sdf_backward_k)) return MSDF_ERR_LAUNCH;
   msdf_sdf_backward_k<<<a->P_pad / MLP_PTS_PER_WG, MLP_THREADS, MLP_LDS_BYTES, (hipStream_t)stream>>>(*plan, *a);

@@ -76,12 +76,12 @@ __global__ void __launch_bounds__(256) msdf_pack_b16_kernel(const msdf_plan_t pl
 template <int NS>
 __global__ void __launch_bounds__(B16_THREADS, 2)
 msdf_sdf_forward_b16_k(const msdf_plan_t plan, const v8bf* __restrict__ wpack, const float* __restrict__ bpack,
-                       const float* __restrict__ x, const float* __restrict__ aux, const int P,
+                       const float* __restrict__ x, const float* __restrict__ aux, const AuxView av, const int P,
                        const float clamp_radius, const float sphere_scale, float* __restrict__ sdf_out,
                        const uint32_t* __restrict__ run_flag) {
   extern __shared__ v8bf lds16[];
   if (run_flag != nullptr && *run_flag == 0u) return;
-  sdf_forward_body<CoreB16N<NS>>(plan, wpack, bpack, x, aux, P, clamp_radius, sphere_scale, sdf_out, lds16);
+  sdf_forward_body<CoreB16N<NS>>(plan, wpack, bpack, x, aux, av, P, clamp_radius, sphere_scale, sdf_out, lds16);
 }
 
 template <int NS>
@@ -116,13 +116,14 @@ int msdf_b16_pack_weights(const msdf_plan_t* plan, const msdf_packrule_t* rules_
 }
 
 int msdf_b16_sdf_forward(const msdf_plan_t* plan, const void* wpack, const float* bpack, const float* x,
-                         const float* aux, int P, float clamp_radius, float sphere_scale, float* sdf,
-                         const uint32_t* run_flag, hipStream_t stream) {
+                         const float* aux, int aux_C, int aux_LC, int P, float clamp_radius, float sphere_scale,
+                         float* sdf, const uint32_t* run_flag, hipStream_t stream) {
   const int grid = (P + B16_PTS_PER_WG - 1) / B16_PTS_PER_WG;
+  const AuxView av = {aux_C, aux_LC, P};
   B16_PLANES(plan, {
     if (b16_prepare<NS>((const void*)msdf_sdf_forward_b16_k<NS>)) return MSDF_ERR_LAUNCH;
     msdf_sdf_forward_b16_k<NS><<<grid, B16_THREADS, B16Cfg<NS>::LDS_BYTES, stream>>>(
-        *plan, (const v8bf*)wpack, bpack, x, aux, P, clamp_radius, sphere_scale, sdf, run_flag);
+        *plan, (const v8bf*)wpack, bpack, x, aux, av, P, clamp_radius, sphere_scale, sdf, run_flag);
   });
   return msdf_check_launch();
 }

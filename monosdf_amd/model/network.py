@@ -203,19 +203,19 @@ class _SdfBase(_FusedNet):
 
     def _sdf_only(self, x, run_flag=None):
         fused, _, _, wpack, bpack = self.packed(x.device)
-        aux = None
+        aux, aux_lm = None, None
         if self.aux_active:
             enc = self.encoding
             if x.shape[-1] == 3 and x.dim() == 2:
-                # x01 inside the encoder kernel, then one LDS-tiled transpose into the SDF kernel's input rows
-                aux = ops.hash_node_features(x, self.divide_factor, enc.embeddings, enc.offsets,
-                                             (enc.num_levels, enc.level_dim, enc.log2_scale, int(enc.base_resolution)),
-                                             16 * fused.plan.aux_tiles)
+                # x01 inside the encoder kernel; the SDF kernel reads the encoder's level-major output
+                aux, aux_lm = ops.hash_node_features(
+                    x, self.divide_factor, enc.embeddings, enc.offsets,
+                    (enc.num_levels, enc.level_dim, enc.log2_scale, int(enc.base_resolution)), 16 * fused.plan.aux_tiles)
             else:
                 with torch.no_grad():
                     aux = self._pad_aux(enc((x / self.divide_factor).detach(), calc_grad_inputs=False))
         radius = self.sdf_bounding_sphere if self.clamps else 0.0
-        return ops.sdf_forward_nograd(fused, wpack, bpack, x.detach(), aux, radius, self.sphere_scale, run_flag)
+        return ops.sdf_forward_nograd(fused, wpack, bpack, x.detach(), aux, radius, self.sphere_scale, run_flag, aux_lm)
 
 
 class ImplicitNetwork(_SdfBase):

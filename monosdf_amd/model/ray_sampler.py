@@ -79,8 +79,12 @@ class ErrorBoundSampler(RaySampler):
         self.scene_bounding_sphere = scene_bounding_sphere
         self.add_tiny = add_tiny
         self._last_rounds = 0
-        self._history = []        # rounds of the last HISTORY calls
-        self._after_miss = 0      # calls left in which all max_total_iters rounds are enqueued (see guess_rounds)
+        # rounds of the last HISTORY calls and the calls left in which all max_total_iters rounds are enqueued (see
+        # guess_rounds) -- kept twice: [0] for this rank's own calls, [1] for the calls whose round decision was
+        # all-reduced over a rank group (global_rounds).  The second one is a function of the all-reduced flags alone,
+        # so it is the same on every rank of the group, and so is the number of rounds (= collectives) guessed from it
+        self._hist = [[], []]
+        self._miss = [0, 0]
         self._pending = None
         self._eval_columns = {}
         # speculation bookkeeping (bench.py reports it): calls, passes repeated because too few rounds were
@@ -152,7 +156,7 @@ class ErrorBoundSampler(RaySampler):
         Returns False if its last enqueued round asked for one more."""
         if self._pending is None:
             return True
-        ev, host, k = self._pending
+        ev, host, k, which = self._pending
         self._pending = None
         ev.synchronize()
         ran = 1
@@ -160,11 +164,11 @@ class ErrorBoundSampler(RaySampler):
             ran += 1
         if ran > k:
             self.stats['repeats'] += 1
-            self._note_rounds(k + 1)
-            self._after_miss = self.HISTORY
+            self._note_rounds(k + 1, which)
+            self._miss[which] = self.HISTORY
             return False
         self.stats['idle_rounds'] += k - ran
-        self._note_rounds(ran)
+        self._note_rounds(ran, which)
         return True
 
     def confirm(self):
@@ -177,19 +181,20 @@ class ErrorBoundSampler(RaySampler):
 
     HISTORY = 32
 
-    def _note_rounds(self, rounds):
+    def _note_rounds(self, rounds, which=0):
         self._last_rounds = rounds
-        self._history = (self._history + [rounds])[-self.HISTORY:]
+        self._hist[which] = (self._hist[which] + [rounds])[-self.HISTORY:]
 
     def guess_rounds(self):
         """Rounds to enqueue for the next call without reading a flag back.  An idle round costs three empty
         launches (~15 us), a round too few costs the whole forward pass again (~10 ms at 1024 rays), so the guess
         errs upwards: the most demanding of the last HISTORY calls, and all max_total_iters rounds for HISTORY calls
         after every miss (small beta: most steps need 2 rounds, one in seven needs 5 -- bench.py, sharp_state)."""
-        if self._after_miss > 0:
-            self._after_miss -= 1
+        which = 1 if self.global_rounds is not None else 0
+        if self._miss[which] > 0:
+            self._miss[which] -= 1
             return self.max_total_iters
-        return max(self._history) if self._history else 1
+        return max(self._hist[which]) if self._hist[which] else 1
 
     def sample(self, ray_dirs, cam_loc, model, want_points=True, speculate=0, beta0=None):
         """get_z_vals plus (optionally) the 3-D points of the ray samples and, in training, the eikonal
@@ -292,11 +297,12 @@ class ErrorBoundSampler(RaySampler):
             a.extra_idx = extra_idx.data_ptr()
 
         group = self.global_rounds
-        if group is not None and speculate > 0:
-            # one all-reduce is enqueued per enqueued round: the count must be the same on every rank, and a
-            # per-rank guess (each rank's own history of calls) is not -- enqueue all rounds; the ones the global
-            # flags do not ask for are no-ops, and a miss cannot happen
-            speculate = K
+        # one all-reduce is enqueued per enqueued round, so the count must be the same on every rank of the group: the
+        # caller's guess comes from guess_rounds(), which in this mode looks only at the history of all-reduced
+        # decisions -- identical on every rank as long as the ranks make their group calls in lockstep (they must:
+        # each one is a collective).  Round 3 enqueued all max_total_iters rounds here: K - 1 idle rounds and
+        # collectives per call in the usual one-round state.
+        which = 1 if group is not None else 0
         rounds = 0
         with torch.no_grad():
             while True:
@@ -329,9 +335,9 @@ class ErrorBoundSampler(RaySampler):
             host.copy_(flags, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-            self._pending = (ev, host, rounds)
+            self._pending = (ev, host, rounds, which)
         else:
-            self._note_rounds(rounds)
+            self._note_rounds(rounds, which)
         # final set: 64 importance samples + near + far + 32 columns of the dense set
         _lib.call('msdf_sampler_finish', C.byref(a), st)
         return z_out, z_eik, x_all

@@ -266,14 +266,16 @@ def fused_weight_norm(state, layers):
 # ---------------------------------------------------------------------------
 # SDF network
 # ---------------------------------------------------------------------------
-def sdf_forward_nograd(mlp, wpack, bpack, x, aux, clamp_radius, sphere_scale, run_flag=None):
+def sdf_forward_nograd(mlp, wpack, bpack, x, aux, clamp_radius, sphere_scale, run_flag=None, aux_lm=None):
     """get_sdf_vals: forward only (sampler).  run_flag: device address of a uint32; the launch does nothing when
-    it holds 0 (a sampler round that the previous round did not ask for)."""
+    it holds 0 (a sampler round that the previous round did not ask for).  aux_lm = (C, L C): `aux` is the hash
+    encoder's level-major tensor [L, P, C] instead of rows [P, 16 * aux_tiles]."""
     x = _need_cuda(x, 'points')
     P = x.shape[0]
     out = torch.empty(P, 1, device=x.device, dtype=torch.float32)
-    _lib.call('msdf_sdf_forward_if', C.byref(mlp.plan), _lib.ptr(wpack), _lib.ptr(bpack),
-              _lib.ptr(x), _lib.ptr(aux), P, float(clamp_radius), float(sphere_scale), _lib.ptr(out),
+    aC, aLC = aux_lm if aux_lm is not None else (0, 0)
+    _lib.call('msdf_sdf_forward_lm', C.byref(mlp.plan), _lib.ptr(wpack), _lib.ptr(bpack),
+              _lib.ptr(x), _lib.ptr(aux), int(aC), int(aLC), P, float(clamp_radius), float(sphere_scale), _lib.ptr(out),
               C.c_void_p(run_flag) if run_flag else None, _lib.stream_ptr())
     return out
 
@@ -286,7 +288,9 @@ class SdfMlpFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, aux, flat_w, flat_b, wpack, bpack, mlp, n_clamp, n_feat, clamp_radius,
-                sphere_scale, save, n_split=None):
+                sphere_scale, save, n_split=None, aux_lm=None):
+        """aux_lm = (C, L C): aux, d sdf / d aux (the last output) and -- in backward -- their gradients are the hash
+        encoder's level-major tensors [L, P, C] instead of rows [P, 16 * aux_tiles]."""
         ctx.set_materialize_grads(False)
         mp = mlp.mp
         plan = mlp.plan
@@ -309,7 +313,9 @@ class SdfMlpFunction(torch.autograd.Function):
         feat_full[n_feat:].zero_()
         feat = feat_full[:n_feat]
         nrm = torch.empty(P, 3, device=dev, dtype=torch.float32)
-        r_aux = torch.empty(P, 16 * plan.aux_tiles, device=dev, dtype=torch.float32) if has_aux else None
+        aC, aLC = aux_lm if (aux_lm is not None and has_aux) else (0, 0)
+        aux_shape = (aLC // aC, P, aC) if aC else (P, 16 * plan.aux_tiles)
+        r_aux = torch.empty(*aux_shape, device=dev, dtype=torch.float32) if has_aux else None
         clamped = torch.empty(max(P, 1), device=dev, dtype=torch.uint8)
         a = _lib.FgArgs()
         a.wpack, a.bpack, a.x, a.aux = wpack.data_ptr(), bpack.data_ptr(), x.data_ptr(), \
@@ -324,10 +330,11 @@ class SdfMlpFunction(torch.autograd.Function):
         a.PM = base + 4 * woff['PM'] if save else None
         a.IN0 = base + 4 * woff['IN0'] if save else None
         a.save = 1 if save else 0
+        a.aux_C, a.aux_LC = int(aC), int(aLC)
         if P > 0:
             _lib.call('msdf_sdf_fwd_grad', C.byref(plan), C.byref(a), _lib.stream_ptr())
         ctx.mlp, ctx.P, ctx.P_pad, ctx.n_feat, ctx.saved = mlp, P, P_pad, n_feat, save
-        ctx.has_aux = has_aux
+        ctx.has_aux, ctx.aux_lm, ctx.aux_shape = has_aux, (int(aC), int(aLC)), aux_shape
         ctx.n_split = ns = P if n_split is None else int(n_split)
         ctx.save_for_backward(x, ws, clamped, wpack, bpack)
         return sdf[:ns], sdf[ns:], feat, nrm[:ns], nrm[ns:], (r_aux if has_aux else None)
@@ -346,8 +353,9 @@ class SdfMlpFunction(torch.autograd.Function):
         cont = lambda t: None if t is None else t.contiguous()
         g_sdf, g_feat, g_nrm, g_raux = cont(g_sdf), cont(g_feat), cont(g_nrm), cont(g_raux)
         g_sdf_b, g_nrm_b = cont(g_sdf_b), cont(g_nrm_b)
-        g_aux = torch.empty(P, 16 * plan.aux_tiles, device=dev, dtype=torch.float32) if ctx.has_aux else None
+        g_aux = torch.empty(*ctx.aux_shape, device=dev, dtype=torch.float32) if ctx.has_aux else None
         b = _lib.BwArgs()
+        b.aux_C, b.aux_LC = ctx.aux_lm
         b.wpack, b.bpack, b.x = wpack.data_ptr(), bpack.data_ptr(), x.data_ptr()
         b.P, b.P_pad, b.n_feat, b.n_split = P, P_pad, ctx.n_feat, ctx.n_split
         b.g_sdf_b = g_sdf_b.data_ptr() if g_sdf_b is not None else None
@@ -374,7 +382,7 @@ class SdfMlpFunction(torch.autograd.Function):
             if between is not None:
                 between(g_aux)
             grad = torch.zeros(mp.n_w + mp.n_b, device=dev)
-        return (None, g_aux, grad[:mp.n_w], grad[mp.n_w:], None, None, None, None, None, None, None, None, None)
+        return (None, g_aux, grad[:mp.n_w], grad[mp.n_w:], None, None, None, None, None, None, None, None, None, None)
 
 
 class _InnerCtx:
@@ -416,23 +424,29 @@ class GridSdfFunction(torch.autograd.Function):
         # own level-major [L, B, C] output; one LDS-tiled transpose turns it into the rows the SDF kernels read
         x01 = torch.empty(B, D, device=x.device, dtype=torch.float32)
         outputs = torch.empty(L, B, Cdim, device=x.device, dtype=torch.float32)
-        aux = torch.empty(B, A, device=x.device, dtype=torch.float32)
         dy_dx = torch.empty(B, L * D * Cdim, device=x.device, dtype=torch.float32)
         st = _lib.stream_ptr()
         _lib.call('msdf_hash_node_forward', _lib.ptr(x), float(divide_factor), _lib.ptr(x01), _lib.ptr(emb),
                   _lib.ptr(offsets), _lib.ptr(outputs), 0, B, Cdim, L, S, H, _lib.ptr(dy_dx), st)
-        _lib.call('msdf_hash_transpose', _lib.ptr(outputs), _lib.ptr(aux), None, None, L, B, Cdim, A, 1, st)
+        # two features per level (every configuration of the reference): the SDF kernels read and write the encoder's
+        # level-major tensors themselves; other channel counts go through rows and the LDS-tiled transpose
+        lm = (Cdim, L * Cdim) if Cdim == 2 else None
+        if lm is not None:
+            aux = outputs
+        else:
+            aux = torch.empty(B, A, device=x.device, dtype=torch.float32)
+            _lib.call('msdf_hash_transpose', _lib.ptr(outputs), _lib.ptr(aux), None, None, L, B, Cdim, A, 1, st)
         inner = _InnerCtx()
         # the grid class never clamps (network.py:290-309): clamp radius 0
         sdf_a, sdf_b, feat, nrm_a, nrm_b, r_aux = SdfMlpFunction.forward(
-            inner, x, aux, flat_w, flat_b, wpack, bpack, mlp, n_clamp, n_feat, 0.0, sphere_scale, save, n_split)
+            inner, x, aux, flat_w, flat_b, wpack, bpack, mlp, n_clamp, n_feat, 0.0, sphere_scale, save, n_split, lm)
         # d sdf / d x through the grid: sum_{l,c} (d sdf / d feature) * d feature / d x01, chain rule to x, added to the
         # MLP's own d sdf / d x in place (nrm_a / nrm_b are the two halves of ONE [B,3] buffer starting at nrm_a)
         k = 0.5 / divide_factor
         assert nrm_a.data_ptr() + 12 * nrm_a.shape[0] == nrm_b.data_ptr() or nrm_b.shape[0] == 0
-        _lib.call('msdf_hash_node_input_gradient', _lib.ptr(r_aux), A, _lib.ptr(dy_dx), B, Cdim, L, float(k),
-                  _lib.ptr(nrm_a), st)
-        ctx.inner, ctx.enc, ctx.k, ctx.n_entries = inner, enc, k, emb.shape[0]
+        _lib.call('msdf_hash_node_input_gradient', _lib.ptr(r_aux), 0 if lm is not None else A, _lib.ptr(dy_dx), B, Cdim,
+                  L, float(k), _lib.ptr(nrm_a), st)
+        ctx.inner, ctx.enc, ctx.k, ctx.n_entries, ctx.lm = inner, enc, k, emb.shape[0], lm
         ctx.offsets = offsets
         ctx.save_for_backward(x01, dy_dx, r_aux, *inner.saved_tensors)
         inner.saved_tensors = ()
@@ -452,13 +466,14 @@ class GridSdfFunction(torch.autograd.Function):
         # gradient arriving at the grid part of d sdf/dx (the reference's grad_grad_inputs, hashgrid.py:71-84), scaled
         # by the chain-rule factor, and its term for d sdf / d feature: grad_grad[b, l C + c] = sum_d gg[b,d] dy_dx --
         # one launch, written as the rows the SDF backward kernel reads
+        lm = ctx.lm
         gg = torch.empty(B, D, device=dev, dtype=torch.float32)
-        g_raux = torch.empty(B, A, device=dev, dtype=torch.float32)
+        g_raux = torch.empty(*((L, B, Cdim) if lm is not None else (B, A)), device=dev, dtype=torch.float32)
         cont = lambda t: None if t is None else t.contiguous()
         g_nrm_c, g_nrm_b_c = cont(g_nrm), cont(g_nrm_b)
         _lib.call('msdf_hash_node_second_grad', _lib.ptr(g_nrm_c) if g_nrm_c is not None else None,
                   _lib.ptr(g_nrm_b_c) if g_nrm_b_c is not None else None, ns, float(k), _lib.ptr(gg), _lib.ptr(dy_dx),
-                  _lib.ptr(g_raux), A, B, Cdim, L, st)
+                  _lib.ptr(g_raux), 0 if lm is not None else A, B, Cdim, L, st)
         done = []
 
         def scatter(g_aux):
@@ -469,10 +484,14 @@ class GridSdfFunction(torch.autograd.Function):
             g_emb = torch.empty(ctx.n_entries, Cdim, device=dev, dtype=torch.float32)
             nbytes = _lib.load().msdf_hash_scatter_workspace_bytes(B, Cdim, L, ctx.n_entries)
             ws = torch.empty(int(nbytes), device=dev, dtype=torch.uint8)
-            # the scatter reads level-major gradients (coalesced): both operands transposed in ONE launch
-            g_lm = torch.empty(2, L, B, Cdim, device=dev, dtype=torch.float32)
-            _lib.call('msdf_hash_transpose', _lib.ptr(g_aux), _lib.ptr(g_lm[0]), _lib.ptr(r_aux), _lib.ptr(g_lm[1]), L, B,
-                      Cdim, A, 0, st)
+            # the scatter reads level-major gradients (coalesced): what the SDF kernels wrote (two features per level),
+            # otherwise both operands transposed in ONE launch
+            if lm is not None:
+                g_lm = (g_aux, r_aux)
+            else:
+                g_lm = torch.empty(2, L, B, Cdim, device=dev, dtype=torch.float32)
+                _lib.call('msdf_hash_transpose', _lib.ptr(g_aux), _lib.ptr(g_lm[0]), _lib.ptr(r_aux), _lib.ptr(g_lm[1]),
+                          L, B, Cdim, A, 0, st)
             _lib.call('msdf_hash_node_scatter', _lib.ptr(g_lm[0]), _lib.ptr(g_lm[1]), 0, _lib.ptr(x01),
                       _lib.ptr(ctx.offsets), _lib.ptr(g_emb), B, Cdim, L, S, H, _lib.ptr(gg), ctx.n_entries,
                       _lib.ptr(ws), int(nbytes), st)
@@ -492,19 +511,23 @@ class GridSdfFunction(torch.autograd.Function):
 
 
 def hash_node_features(x, divide_factor, embeddings, offsets, enc, pitch):
-    """Grid features of the points x (world coordinates) as rows of `pitch` floats, no gradient: what the sampler's SDF
-    evaluations feed the fused forward kernel -- x01 inside the encoder kernel, then one LDS-tiled transpose."""
+    """Grid features of the points x (world coordinates), no gradient: what the sampler's SDF evaluations feed the fused
+    forward kernel -- x01 inside the encoder kernel.  Returns (tensor, aux_lm): the encoder's level-major [L, B, C]
+    tensor with aux_lm = (C, L C) for two features per level, else rows of `pitch` floats (one LDS-tiled transpose)
+    with aux_lm = None."""
     x = _need_cuda(x.detach(), 'points')
     emb = _need_cuda(embeddings.detach(), 'embeddings')
     L, Cdim, S, H = enc
     B = x.shape[0]
     st = _lib.stream_ptr()
     outputs = torch.empty(L, B, Cdim, device=x.device, dtype=torch.float32)
-    aux = torch.empty(B, pitch, device=x.device, dtype=torch.float32)
     _lib.call('msdf_hash_node_forward', _lib.ptr(x), float(divide_factor), None, _lib.ptr(emb), _lib.ptr(offsets),
               _lib.ptr(outputs), 0, B, Cdim, L, S, H, None, st)
+    if Cdim == 2:
+        return outputs, (Cdim, L * Cdim)          # the SDF kernel reads the level-major tensor itself
+    aux = torch.empty(B, pitch, device=x.device, dtype=torch.float32)
     _lib.call('msdf_hash_transpose', _lib.ptr(outputs), _lib.ptr(aux), None, None, L, B, Cdim, pitch, 1, st)
-    return aux
+    return aux, None
 
 
 # ---------------------------------------------------------------------------

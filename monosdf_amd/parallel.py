@@ -33,7 +33,8 @@ def shard_slice(n_items, rank_=None, world_=None):
 # pass (the weight-gradient kernels) is still running -- the comm stream waits for the mark, not for the stream.
 # ---------------------------------------------------------------------------
 _LISTENERS = 0          # GradientAverager objects with an overlapped block (nobody listening: no event is recorded)
-_GRAD_READY = {}        # data_ptr of the gradient tensor -> event recorded behind the kernel that completed it
+_GRAD_READY = {}        # data_ptr of the gradient tensor -> (tensor, its version counter, event recorded behind the
+                        # kernel that completed it)
 
 
 def mark_grad_ready(t):
@@ -43,7 +44,24 @@ def mark_grad_ready(t):
             _GRAD_READY.clear()
         ev = torch.cuda.Event()
         ev.record()
-        _GRAD_READY[t.data_ptr()] = ev
+        _GRAD_READY[t.data_ptr()] = (t, t._version, ev)
+
+
+def grad_ready_event(g):
+    """The event behind which gradient tensor ``g`` is complete, or None when that is not known.  Only for the very
+    tensor that was marked and only while nothing has written to it since: when autograd ADDS a second contribution
+    into the marked tensor in place (two nodes feeding one table in the same backward pass) the address is the same
+    but the version counter has moved, and when it clones or accumulates into another tensor an old entry may sit at
+    a recycled address -- in both cases the caller has to wait for the stream instead."""
+    if not g.is_cuda:
+        return None
+    entry = _GRAD_READY.pop(g.data_ptr(), None)
+    if entry is None:
+        return None
+    t, version, ev = entry
+    if t is g and g._version == version:
+        return ev
+    return None
 
 
 class GradientAverager:
@@ -137,7 +155,7 @@ class GradientAverager:
 
     def _grad_arrived(self, p):
         if self._world() > 1 and p.grad is not None:
-            self._reduce_big(p, _GRAD_READY.pop(p.grad.data_ptr(), None) if p.grad.is_cuda else None)
+            self._reduce_big(p, grad_ready_event(p.grad))
 
     def average(self, group=None):
         if group is not None:
@@ -183,6 +201,7 @@ class GradientAverager:
                 work.wait()
             if op != dist.ReduceOp.AVG:
                 p.grad.div_(w)
+        _GRAD_READY.clear()            # marks that no hook consumed belong to this pass: never to a later tensor
         return self.flat
 
 

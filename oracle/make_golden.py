@@ -83,6 +83,9 @@ CASES = {
     'mlp_w64_train': dict(kind='mlp', width=64, n_rays=24, jitter=0.3, training=True, grads=True),
     'mlp_w64_train_sharp': dict(kind='mlp', width=64, n_rays=16, jitter=0.1, beta=0.01, training=True, grads=True),
     'mlp_w64_image_eval': dict(kind='mlp', width=64, n_rays=20, jitter=0.3, training=False, image_mode=True),
+    # image-mode (uv + pose + intrinsics) input AND training together: the yardstick case of the uv-input training rows
+    # of tests/test_gpu_shapes.py (round 3 held them to hand-written bars)
+    'mlp_w64_image_train': dict(kind='mlp', width=64, n_rays=20, jitter=0.3, training=True, grads=True, image_mode=True),
     'mlp_w64_white_train': dict(kind='mlp', width=64, n_rays=12, jitter=0.3, training=True, grads=True,
                                 white_bkgd=True),
     'mlp_w64_code_train': dict(kind='mlp', width=64, n_rays=12, jitter=0.3, training=True, grads=True,

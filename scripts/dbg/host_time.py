@@ -53,7 +53,7 @@ print("speculate 'all': host enqueue %.2f ms/step, wall %.2f ms/step" % (1e3 * t
 small = [bench.make_rays(16, 100 + b, 'cuda') for b in range(8)]
 idx16 = torch.arange(16, device='cuda')
 batches, idx = small, idx16
-model.ray_sampler._history = []
+model.ray_sampler._hist[0] = []
 for i in range(5):
     step(i)
 torch.cuda.synchronize()

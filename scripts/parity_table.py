@@ -8,6 +8,11 @@ This tool never widens the table by itself:
     python scripts/parity_table.py tighten gpurun_out/parity_errors.json [rNN]      # LOWER entries to 2 x measured, drop
                                                                                     # entries now under half the bar
     python scripts/parity_table.py add gpurun_out/parity_errors.json rNN 'test|case|key' ['hand-written cause']
+    python scripts/parity_table.py prune gpurun_out/parity_errors.json rNN          # drop entries of comparisons that no
+                                                                                    # longer exist (their test ran, they did not)
+`check` also writes profiles/rNN_parity_admitted.txt: per fp32 row above 1e-4, which yardstick kinds admit it taken alone.
+A NEW yardstick kind must be listed in the table's `yardstick_kinds` first (tests/test_host_logic.py refuses kinds that
+are not), in a commit of its own: never together with rows it admits.
 
 `check` exits non-zero when a measured error exceeds its tolerance (1e-4 for a comparison not in the table) or when
 an entry breaks the rule below.  `tighten` only lowers.  `add` is the one way an entry comes into being: it is
@@ -35,7 +40,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BAR = 1e-4
 TABLE = os.path.join(ROOT, 'tests', 'golden', 'tolerances.json')
-YARD = os.path.join(ROOT, 'profiles', 'r03_reference_sensitivity.json')
+# round 4 adds the image-mode training case to round 3's file (scripts/reference_sensitivity.py --only ...)
+YARD = next(p for p in (os.path.join(ROOT, 'profiles', 'r04_reference_sensitivity.json'),
+                        os.path.join(ROOT, 'profiles', 'r03_reference_sensitivity.json')) if os.path.exists(p))
 B16_FLOOR = 8e-4
 B16_SDF_RATIO = 13.0          # measured |sdf - reference| of the bf16x3 core / the yardstick's 1e-6
 OWN_TOL = ('sampler_rounds', 'stages', 'trajectory', 'trajectory.bf16x6')        # tolerances stated in the tests themselves
@@ -61,6 +68,37 @@ def yardstick(yard, test, case, key):
         if v is not None and (best[0] is None or v > best[0]):
             best = (v, kind)
     return best
+
+
+def admitting_kinds(yard, test, case, key, tol):
+    """Which of the yardstick kinds, each taken ALONE, admit this tolerance under the rule (tol <= max(1e-4, 2 y) + 10 %)."""
+    ent = yard.get(case)
+    if ent is None:
+        return []
+    if test.startswith(('forward_golden', 'sampler_golden')):
+        k = 'out.' + key
+    elif test.startswith('gradients_golden'):
+        k = 'grad.' + key.split('(')[0]
+    else:
+        return []
+    return [kind for kind in KINDS if ent.get(kind, {}).get(k) is not None and tol <= bound(test, ent[kind][k])]
+
+
+def admitted_report(table, yard):
+    """Per fp32-core row above the bar: the kinds that admit it.  Returns (lines, rows admitted by (c) alone, rows no kind admits)."""
+    lines, c_only, none = [], [], []
+    for k, ent in sorted(table.items()):
+        test, case, key = k.split('|')
+        if 'bf16x3' in test or ent['tol'] <= BAR:
+            continue
+        kinds = admitting_kinds(yard, test, case, key, ent['tol'])
+        lines.append('%-100s tol %.1e  admitted by: %s%s' % (k, ent['tol'], ', '.join(kinds) if kinds else 'none',
+                                                            '  [hand-written cause]' if ent.get('hand') else ''))
+        if kinds == ['perturbed_sdf_abs']:
+            c_only.append(k)
+        if not kinds:
+            none.append(k)
+    return lines, c_only, none
 
 
 def bound(test, y):
@@ -171,6 +209,18 @@ def main(argv):
                 n_low += 1
         save(doc)
         print('tightened %d entries, dropped %d (now %d)' % (n_low, n_drop, len(table)))
+    elif mode == 'prune':
+        # entries of comparisons that no longer exist: their test family was measured in this (full) run, they were not
+        families = {t for (t, _, _) in worst}
+        gone = [k for k in table if k.split('|')[0] in families and tuple(k.split('|')) not in worst]
+        for k in gone:
+            del table[k]
+            print('pruned %s' % k)
+        save(doc)
+    elif mode == 'annotate':
+        key, text = argv[4], argv[5]
+        table[key]['cause'] = table[key]['cause'].rstrip() + ' -- ' + text
+        save(doc)
     elif mode == 'add':
         key = argv[4]
         hand = argv[5] if len(argv) > 5 else None
@@ -206,6 +256,15 @@ def main(argv):
         print('BREAKS THE RULE: %s tol %.1e, yardstick %s and no hand-written cause' % (k, tol, y))
         rc = 1
     write_md(rnd, worst, table, yard, src)
+    lines, c_only, none = admitted_report(table, yard)
+    with open(os.path.join(ROOT, 'profiles', '%s_parity_admitted.txt' % rnd), 'w') as f:
+        f.write('fp32-core rows of tests/golden/tolerances.json above 1e-4 and the yardstick kinds that admit each, taken '
+                'alone\n(fp64 = the reference against exact arithmetic, perturbed_sdf = its sampler\'s SDF values changed by '
+                '1e-6 relative,\nperturbed_sdf_abs = by 1e-6 of max|sdf| -- kind (c), introduced in round 3)\n\n')
+        f.write('\n'.join(lines) + '\n\n%d rows; %d admitted by (c) perturbed_sdf_abs ALONE; %d by no stored yardstick '
+                '(hand-written cause or a comparison without a golden case)\n' % (len(lines), len(c_only), len(none)))
+    print('fp32 rows above 1e-4: %d; admitted by yardstick (c) alone: %d; by no stored yardstick: %d  (profiles/%s_parity_admitted.txt)'
+          % (len(lines), len(c_only), len(none), rnd))
     f32 = [k for k, e in table.items() if 'bf16x3' not in k and e['tol'] > BAR]
     print('%d comparisons measured; table: %d entries, %d on the fp32 core above 1e-4, %d with a hand-written cause; '
           'worst measured %.2e' % (len(worst), len(table), len(f32), sum(1 for e in table.values() if e.get('hand')),

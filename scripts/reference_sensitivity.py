@@ -44,14 +44,19 @@ TRIALS = 16
 def run(c, gen=None, absolute=False):
     state = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in c.state.items()}
     z_override = None
-    if gen is not None and c.pixel:
+    if gen is not None:
         def fn(p):
             s = mo.get_sdf_vals(c.state, c.conf, p)
             u = 2 * torch.rand(s.shape, generator=gen) - 1
             return s + EPS * s.abs().max() * u if absolute else s * (1 + EPS * u)
+        if c.pixel:
+            dirs, cam = c.inputs['ray_dirs'], c.inputs['ray_cam_loc']
+        else:        # image mode (round 4): the rays render() forms from uv / pose / intrinsics
+            dirs, cam = mo.camera_rays(c.inputs['uv'], c.inputs['pose'], c.inputs['intrinsics'])
+            cam = cam.unsqueeze(1).repeat(1, dirs.shape[1], 1).reshape(-1, 3)
+            dirs = dirs.reshape(-1, 3)
         with torch.no_grad():
-            z_override = mo.error_bound_sampler(c.state, c.conf, c.inputs['ray_dirs'], c.inputs['ray_cam_loc'],
-                                                c.training, c.noise, sdf_fn=fn)
+            z_override = mo.error_bound_sampler(c.state, c.conf, dirs, cam, c.training, c.noise, sdf_fn=fn)
     out = mo.render(state, c.conf, c.inputs, c.indices, c.pixel, c.training, c.noise, z_override=z_override,
                     if_hdr=c.spec.get('if_hdr', False))
     grads = {}
@@ -63,13 +68,35 @@ def run(c, gen=None, absolute=False):
 
 
 def main():
+    """No argument: every pixel-mode golden case -> profiles/r03_reference_sensitivity.json (round 3's run).
+    `--only case [case ...]` (round 4): the named cases (image-mode ones too), their fp32-vs-fp64 figures computed here
+    with scripts/reference_conditioning.run, merged with round 3's file into profiles/r04_reference_sensitivity.json."""
+    only = sys.argv[sys.argv.index('--only') + 1:] if '--only' in sys.argv else None
     fp64_path = os.path.join(ROOT, 'profiles', 'r02_reference_conditioning.json')
     fp64 = json.load(open(fp64_path)) if os.path.exists(fp64_path) else {}
     res = {'eps': EPS, 'trials': TRIALS, 'cases': {}}
-    for name in ALL_CASES:
+    out_path = os.path.join(ROOT, 'profiles', 'r03_reference_sensitivity.json')
+    if only:
+        import reference_conditioning as rc
+        res = json.load(open(out_path))
+        out_path = os.path.join(ROOT, 'profiles', 'r04_reference_sensitivity.json')
+        if os.path.exists(out_path):
+            res = json.load(open(out_path))
+        for name in only:
+            c = Case(name)
+            o32, g32 = rc.run(c, torch.float32)
+            ent = {}
+            for variant in ((False, True) if c.pixel else (False,)):
+                o64, g64 = rc.run(c, torch.float64, variant)
+                for k in o32:
+                    ent['out.' + k] = max(ent.get('out.' + k, 0.0), rel_err(o32[k], o64[k]))
+                for k in g32:
+                    ent['grad.' + k] = max(ent.get('grad.' + k, 0.0), rel_err(g32[k], g64[k]))
+            fp64[name] = ent
+    for name in (only or ALL_CASES):
         c = Case(name)
-        if not c.pixel:
-            continue              # image-mode case: rays come from uv inside render(); covered by its pixel twin
+        if not c.pixel and not only:
+            continue              # round 3: image-mode cases were left to their pixel twins
         o0, g0 = run(c)
         both = {}
         for absolute in (False, True):
@@ -89,7 +116,7 @@ def main():
         res['cases'][name] = dict(both, fp64=fp64.get(name, {}))
         worst = sorted(ent.items(), key=lambda kv: -kv[1])[:3]
         print('%-24s %s' % (name, ', '.join('%s %.1e' % kv for kv in worst)), flush=True)
-    json.dump(res, open(os.path.join(ROOT, 'profiles', 'r03_reference_sensitivity.json'), 'w'), indent=1, sort_keys=True)
+    json.dump(res, open(out_path, 'w'), indent=1, sort_keys=True)
 
 
 if __name__ == '__main__':

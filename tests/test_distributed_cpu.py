@@ -384,7 +384,7 @@ def _bench(*argv, env=None):
                           text=True, timeout=600)
 
 
-@pytest.mark.parametrize('n', [2, 3])
+@pytest.mark.parametrize('n', [2, 3, 8])
 def test_bench_launcher_starts_n_ranks(n):
     import json
     r = _bench('--gpus', str(n), '--steps', '2', '--dry-run')
@@ -407,3 +407,23 @@ def test_bench_launcher_refuses_fewer_devices_than_ranks():
 def test_bench_refuses_world_size_mismatch():
     r = _bench('--gpus', '4', '--steps', '1', '--dry-run', env={'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0'})
     assert r.returncode != 0 and 'launcher started 1 rank' in r.stderr and r.stdout.strip() == ''
+
+
+def test_bench_rank_that_does_not_arrive_is_named_quickly():
+    """A rank that never comes up must not hold the others for torch.distributed's default 10 minutes (the driver's
+    whole limit): with a 4-second rendezvous limit, rank 0 of a two-rank job whose rank 1 is never started gives up,
+    names rank 1 on its (rank-prefixed) stderr and exits non-zero without printing a line."""
+    import socket
+    import time
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    t0 = time.time()
+    r = _bench('--gpus', '2', '--steps', '1', '--dry-run',
+               env={'WORLD_SIZE': '2', 'RANK': '0', 'LOCAL_RANK': '0', 'MASTER_ADDR': '127.0.0.1',
+                    'MASTER_PORT': str(port), 'MSDF_RDZV_TIMEOUT': '4'})
+    assert r.returncode == 3, (r.returncode, r.stderr[-1500:])
+    assert 'rank(s) 1 of 2 did not arrive' in r.stderr and '[rank 0] ' in r.stderr
+    assert r.stdout.strip() == ''
+    assert time.time() - t0 < 120

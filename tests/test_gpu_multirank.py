@@ -61,6 +61,11 @@ def _worker(rank, world, port, q):
             rounds[mode + '_global'] = m.ray_sampler.last_rounds
             rows = torch.cat([out['z_vals'], out['rgb_values'], out['depth_values'], out['normal_map']], 1)
             res[mode] = parallel.all_gather_rows(rows.detach()).cpu()
+        # the number of rounds (= collectives) a rank enqueues for the next group call comes from the all-reduced
+        # decisions alone: the same on every rank, whatever each rank's own calls needed in between
+        m.ray_sampler.global_rounds = True
+        res['global_guess'] = (m.ray_sampler.guess_rounds(), list(m.ray_sampler._hist[1]))
+        res['own_history'] = list(m.ray_sampler._hist[0])
         m.ray_sampler.global_rounds = None
         m.speculate_rounds = False
         full = m({k: v.cuda() for k, v in c.inputs.items()}, c.indices.cuda(), if_pixel_input=True)
@@ -121,6 +126,38 @@ def _worker(rank, world, port, q):
         res['avg_err'] = max(float((p_.grad - want[n_]).abs().max() / (want[n_].abs().max() + 1e-20)) for n_, p_ in named)
         res['avg_overlapped_ms'] = [a_.elapsed_time(b_) for a_, b_ in avg.timings['overlapped']]
         avg.close()
+        # 5. the table feeds TWO nodes of one backward pass (the network evaluated on two point sets): autograd adds the
+        # second scatter's result into the first one's tensor in place -- same address, which carries the first scatter's
+        # "complete" mark.  The mark must not be trusted then (parallel.grad_ready_event: tensor identity + version).
+        net = mg.implicit_network
+        gen = torch.Generator().manual_seed(3)
+        xa, xb = (torch.rand(2, 2, 150, 3, generator=gen) * 1.6 - 0.8).cuda().unbind(0)
+
+        def twice(r_):
+            for p_ in mg.parameters():
+                p_.grad = None
+            sa, fa, ga = net.get_outputs(xa[r_])
+            sb, fb, gb = net.get_outputs(xb[r_])
+            (sa.sum() + 0.1 * fa.sum() + ga.sum() + 2.0 * sb.sum() + 0.3 * gb.pow(2).sum()).backward()
+        want2 = {}
+        for r_ in range(2):
+            twice(r_)
+            for n_, p_ in named:
+                if p_.grad is not None:
+                    want2[n_] = want2.get(n_, 0) + p_.grad.detach().clone() / 2
+        seen = []
+        orig_ready = parallel.grad_ready_event
+        parallel.grad_ready_event = lambda g_: seen.append(orig_ready(g_)) or seen[-1]
+        avg2 = parallel.GradientAverager([p_ for n_, p_ in named if n_ in want2], overlap_min_numel=8000)
+        twice(rank)
+        avg2.average()
+        torch.cuda.synchronize()
+        parallel.grad_ready_event = orig_ready
+        res['twice_err'] = max(float((p_.grad - want2[n_]).abs().max() / (want2[n_].abs().max() + 1e-20))
+                               for n_, p_ in named if n_ in want2)
+        res['twice_marks_trusted'] = [e_ is not None for e_ in seen]
+        res['twice_marks_left'] = len(parallel._GRAD_READY)
+        avg2.close()
         # plain numpy in the queue: a tensor would travel as a shared-memory handle that dies with this process
         def plain(v):
             if torch.is_tensor(v):
@@ -167,5 +204,11 @@ def test_two_ranks_on_one_gpu():
         assert res['avg_big'] == ['implicit_network.encoding.embeddings']
         assert res['avg_started_in_backward'] == 1 and len(res['avg_overlapped_ms']) == 1
         assert res['avg_err'] < 2e-6, res['avg_err']
+        # two nodes, one table: one hook call, its tensor was written after the first mark -> not trusted; nothing left over
+        assert res['twice_marks_trusted'] == [False], res['twice_marks_trusted']
+        assert res['twice_marks_left'] == 0
+        assert res['twice_err'] < 2e-6, res['twice_err']
+    assert allres[0]['global_guess'] == allres[1]['global_guess'] and allres[0]['global_guess'][0] == 5
+    assert allres[0]['own_history'] != allres[1]['own_history']          # each rank's own calls differ (3 vs 5 rounds)
     # left alone, the second shard stops after its own 3 rounds (what makes the all-reduce necessary)
     assert sorted(r['rounds']['sync_alone'] for r in allres) == [3, 5]

@@ -285,7 +285,7 @@ def test_round_count_guessed_from_history(name, history):
     m = _model(c)
     ref_out, ref_grads = _run(m, c, False)
     stats0 = dict(m.ray_sampler.stats)
-    m.ray_sampler._history = list(history)
+    m.ray_sampler._hist[0] = list(history)
     out, grads = _run(m, c, True)
     assert m.ray_sampler.last_rounds == c.rounds
     d = {k: m.ray_sampler.stats[k] - stats0[k] for k in stats0}

@@ -280,9 +280,43 @@ def test_tiny_and_empty_point_sets(P):
     assert rel_err(vals, mo.get_sdf_vals(st, conf, x)) < TOL
 
 
+@pytest.mark.parametrize('P', [0, 1, 17, 65])
+def test_tiny_and_empty_point_sets_grid_model(P):
+    """The same on the hash-grid network (encoder node forms + level-major feature tensors): an empty point set has
+    NULL tensors and must come back as empty outputs and an all-zero table gradient, not as an argument error."""
+    from oracle import monosdf_oracle as mo
+    from monosdf_amd.conf import ConfigTree
+    from monosdf_amd.model.network import MonoSDFNetwork
+    conf = config.grid_config(64, 0.1, 4, 2, 11, 8, 64)
+    state = synth.make_state(conf, seed=5, jitter=0.3)
+    m = MonoSDFNetwork(ConfigTree.from_dict(conf))
+    m.load_state_dict({k: v.clone() for k, v in state.items()}, strict=True)
+    m = m.cuda().train()
+    net = m.implicit_network
+    g = torch.Generator().manual_seed(P + 3)
+    x = (torch.rand(P, 3, generator=g) * 2 - 1)
+    with torch.no_grad():
+        vals = net.get_sdf_vals(x.cuda())
+    sdf, feat, grad = net.get_outputs(x.cuda())
+    assert vals.shape == (P, 1) and sdf.shape == (P, 1) and grad.shape == (P, 3)
+    assert feat.shape == (P, conf['feature_vector_size'])
+    (sdf.sum() + feat.sum() * 0.1 + grad.sum()).backward()
+    emb = net.encoding.embeddings
+    assert emb.grad is not None and emb.grad.shape == emb.shape and torch.isfinite(emb.grad).all()
+    if P == 0:
+        assert float(emb.grad.abs().max()) == 0.0
+        return
+    st = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in state.items()}
+    sdf_o, feat_o, grad_o = mo.get_outputs(st, conf, x)
+    assert rel_err(sdf, sdf_o) < TOL and rel_err(feat, feat_o) < TOL and rel_err(grad, grad_o) < TOL
+    assert rel_err(vals, mo.get_sdf_vals(st, conf, x)) < TOL
+    (sdf_o.sum() + feat_o.sum() * 0.1 + grad_o.sum()).backward()
+    assert rel_err(emb.grad, st['implicit_network.encoding.embeddings'].grad) < 2e-4
+
+
 MODE_VARIANTS = {
     # (image mode, training, white background, per-image code, if_hdr)
-    'image_train': (True, True, False, False, False),
+    # uv input + training without options: tests/golden/mlp_w64_image_train.npz (recorded from the reference, round 4)
     'image_train_code_white': (True, True, True, True, False),
     'pixel_eval_white_hdr': (False, False, True, False, True),
     'pixel_train_code_hdr': (False, True, False, True, True),
