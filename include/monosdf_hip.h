@@ -187,7 +187,11 @@ typedef struct {
   int32_t aux_C;           /* layout of aux / r_aux: 0 = rows [P, 16*aux_tiles]; C = 1, 2, 4, 8: the hash encoder's own
                               level-major tensors [aux_LC / C][P][C] (column l C + c of a point = level l, channel c) */
   int32_t aux_LC;          /* valid columns (levels x channels) of the level-major form */
-  int32_t pad_;
+  float aux_dx_scale;      /* with dy_dx: the chain-rule factor of x -> x01 (0.5 / divide_factor) */
+  const float* dy_dx;      /* NULL, or (aux_C == 2 only) the hash encoder's Jacobian [L][P][3][2] as
+                              msdf_hash_node_forward writes it: nrm then also holds the grid part of d sdf / d x,
+                              nrm += aux_dx_scale * sum_{l,c} r_aux[l,c] dy_dx[l,.,c] (what msdf_hash_node_input_gradient
+                              adds as a launch of its own; reference kernel_input_backward, hashencoder.cu:346-372) */
 } msdf_fg_args_t;
 int msdf_sdf_fwd_grad(const msdf_plan_t* plan, const msdf_fg_args_t* args, void* stream);
 
@@ -217,6 +221,14 @@ typedef struct {
   const float* g_sdf_b;    /* [P - n_split] or NULL */
   const float* g_nrm_b;    /* [P - n_split, 3] or NULL */
   int32_t aux_C, aux_LC;   /* layout of g_raux / g_aux, as in msdf_fg_args_t */
+  const float* dy_dx;      /* NULL, or (aux_C == 2 only) the encoder's Jacobian [L][P][3][2]: the gradient arriving at
+                              d sdf / d features from the grid part of d sdf / d x is then formed in the kernel from
+                              g_nrm, g_raux[l,c] = sum_d (aux_dx_scale g_nrm[d]) dy_dx[l,d,c] (g_raux itself is ignored) --
+                              what msdf_hash_node_second_grad computes as a launch of its own (reference
+                              kernel_grid_second_backward_grad, hashencoder.cu:375-428), bit-identical to it */
+  float* gg_out;           /* with dy_dx: [P,3] <- aux_dx_scale * g_nrm (the scatter's grad_grad_inputs), or NULL */
+  float aux_dx_scale;
+  int32_t pad_;
 } msdf_bw_args_t;
 int msdf_sdf_backward(const msdf_plan_t* plan, const msdf_bw_args_t* args, void* stream);
 

@@ -55,7 +55,7 @@ class FgArgs(C.Structure):
                 ('clamp_radius', C.c_float), ('sphere_scale', C.c_float),
                 ('sdf', _P), ('feat', _P), ('nrm', _P), ('r_aux', _P), ('clamped', _P),
                 ('H', _P), ('PM', _P), ('IN0', _P), ('save', C.c_int32), ('aux_C', C.c_int32), ('aux_LC', C.c_int32),
-                ('pad_', C.c_int32)]
+                ('aux_dx_scale', C.c_float), ('dy_dx', _P)]
 
 
 class BwArgs(C.Structure):
@@ -63,7 +63,8 @@ class BwArgs(C.Structure):
                 ('P', C.c_int32), ('P_pad', C.c_int32), ('n_feat', C.c_int32), ('n_split', C.c_int32),
                 ('g_sdf', _P), ('g_feat', _P), ('g_nrm', _P), ('g_raux', _P), ('clamped', _P),
                 ('H', _P), ('PM', _P), ('QB', _P), ('T', _P), ('AB', _P), ('GSDF', _P), ('QLAST', _P),
-                ('g_aux', _P), ('g_sdf_b', _P), ('g_nrm_b', _P), ('aux_C', C.c_int32), ('aux_LC', C.c_int32)]
+                ('g_aux', _P), ('g_sdf_b', _P), ('g_nrm_b', _P), ('aux_C', C.c_int32), ('aux_LC', C.c_int32),
+                ('dy_dx', _P), ('gg_out', _P), ('aux_dx_scale', C.c_float), ('pad_', C.c_int32)]
 
 
 class ColorFwdArgs(C.Structure):

@@ -64,6 +64,50 @@ __device__ __forceinline__ void aux_store_tile(float* __restrict__ base, const A
   if (s0 + 2 < av.LC) *(v2f_aux*)(base + ((size_t)(l + 1) * av.P + pt) * 2) = (v2f_aux){v.z, v.w};
 }
 
+// The hash encoder's Jacobian d feature / d x01, level-major [L][P][3][2] (two features per level), applied inside the
+// SDF kernels instead of by two kernels of their own (hg_node_input_gradient / hg_node_second_grad, csrc/hashgrid.hip --
+// the reference's kernel_input_backward and kernel_grid_second_backward_grad, hashencoder.cu:346-428): a lane owns four
+// levels of its point (two per aux tile) and reads their 6 floats as three 8-byte pieces.
+// grid part of d sdf / d x:  m_d = sum over the lane's (level, channel) of r[l,c] * J[l,d,c]   (summed over the quarters by the caller)
+__device__ __forceinline__ void aux_jacobian_transpose(const float* __restrict__ dy_dx, const AuxView av,
+                                                       const int aux_tiles, const v4f (&r)[2], const int pt, const int q,
+                                                       float& m0, float& m1, float& m2) {
+  m0 = m1 = m2 = 0.f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int s0 = 16 * t + 4 * q + 2 * h;
+      if (t < aux_tiles && s0 < av.LC) {
+        const float* d = dy_dx + ((size_t)(s0 >> 1) * av.P + pt) * 6;
+        const v2f_aux j0 = *(const v2f_aux*)d, j1 = *(const v2f_aux*)(d + 2), j2 = *(const v2f_aux*)(d + 4);
+        const float g0 = r[t][2 * h], g1 = r[t][2 * h + 1];
+        m0 += g0 * j0.x + g1 * j0.y;
+        m1 += g0 * j1.x + g1 * j1.y;
+        m2 += g0 * j2.x + g1 * j2.y;
+      }
+    }
+  }
+}
+
+// gradient arriving at d sdf / d features from the grid part of d sdf / d x:  out[l,c] = sum_d g_d * J[l,d,c], each product
+// and sum rounded separately, in the order of hg_node_second_grad_kernel (bit-identical to that kernel)
+__device__ __forceinline__ v4f aux_jacobian_tile(const float* __restrict__ dy_dx, const AuxView av, const int t,
+                                                 const int pt, const int q, const float g0, const float g1, const float g2) {
+  v4f v = V4ZERO;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int s0 = 16 * t + 4 * q + 2 * h;
+    if (s0 < av.LC) {
+      const float* d = dy_dx + ((size_t)(s0 >> 1) * av.P + pt) * 6;
+      const v2f_aux j0 = *(const v2f_aux*)d, j1 = *(const v2f_aux*)(d + 2), j2 = *(const v2f_aux*)(d + 4);
+      v[2 * h] = __fadd_rn(__fadd_rn(__fmul_rn(g0, j0.x), __fmul_rn(g1, j1.x)), __fmul_rn(g2, j2.x));
+      v[2 * h + 1] = __fadd_rn(__fadd_rn(__fmul_rn(g0, j0.y), __fmul_rn(g1, j1.y)), __fmul_rn(g2, j2.y));
+    }
+  }
+  return v;
+}
+
 // network input tiles: PE tiles then aux tiles (hash-grid features)
 __device__ __forceinline__ void load_input_tiles(v4f (&in0)[5], const msdf_plan_t& plan,
                                                  const float* __restrict__ aux, const AuxView av, const PointCtx& c) {
@@ -417,6 +461,15 @@ __device__ __forceinline__ void sdf_fwd_grad_body(const msdf_plan_t& plan, const
     if (l == 0) take_input_grad(0);
     else if (L.skip_tile >= 0) take_input_grad(L.skip_tile);
   }
+  // d sdf / d x through the hash grid (its chain-rule factor a.aux_dx_scale in), added as the module's tensor
+  // expression adds it: the rounded product, then the sum
+  if (a.dy_dx != nullptr && plan.aux_tiles > 0) {
+    float m0, m1, m2;
+    aux_jacobian_transpose(a.dy_dx, av, plan.aux_tiles, r_aux, c.ptc, c.q, m0, m1, m2);
+    n0 = __fadd_rn(n0, __fmul_rn(sum_over_quarters(m0), a.aux_dx_scale));
+    n1 = __fadd_rn(n1, __fmul_rn(sum_over_quarters(m1), a.aux_dx_scale));
+    n2 = __fadd_rn(n2, __fmul_rn(sum_over_quarters(m2), a.aux_dx_scale));
+  }
   // ---------------- clamp, stores ----------------
   bool is_clamped = false;
   if (a.clamp_radius > 0.f && c.pt < a.n_clamp) {
@@ -462,7 +515,14 @@ __device__ __forceinline__ void load_rbar(v4f (&rbar)[5], const msdf_plan_t& pla
                                           const float gn2) {
   pe_jacobian(rbar, c.x0, c.x1, c.x2, plan.n_freqs, gn0, gn1, gn2);
   rbar[3] = rbar[4] = V4ZERO;
-  if (a.g_raux != nullptr && live) {
+  if (a.dy_dx != nullptr && live) {
+    // formed here from the encoder's Jacobian instead of read from a tensor a kernel of its own wrote
+    const AuxView av = {a.aux_C, a.aux_LC, a.P};
+    const float g0 = __fmul_rn(gn0, a.aux_dx_scale), g1 = __fmul_rn(gn1, a.aux_dx_scale), g2 = __fmul_rn(gn2, a.aux_dx_scale);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      if (t < plan.aux_tiles) rbar[3 + t] = aux_jacobian_tile(a.dy_dx, av, t, c.pt, c.q, g0, g1, g2);
+  } else if (a.g_raux != nullptr && live) {
     const AuxView av = {a.aux_C, a.aux_LC, a.P};
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -492,6 +552,20 @@ __device__ __forceinline__ void sdf_backward_body(const msdf_plan_t& plan, const
     }
   }
   if (c.q == 0) a.GSDF[c.pt] = gs;
+  if (a.gg_out != nullptr && c.valid && c.q == 0) {
+    // the scaled gradient of d sdf / d x, which the embedding scatter's second-order term reads per point (also for
+    // clamped points, as hg_node_second_grad_kernel writes it: their d sdf / d features is zero, so nothing comes of it)
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+    const bool first = c.pt < a.n_split;
+    const float* gnp = first ? a.g_nrm : a.g_nrm_b;
+    if (gnp != nullptr) {
+      const size_t j = first ? (size_t)c.pt : (size_t)(c.pt - a.n_split);
+      r0 = gnp[j * 3 + 0]; r1 = gnp[j * 3 + 1]; r2 = gnp[j * 3 + 2];
+    }
+    a.gg_out[(size_t)c.pt * 3 + 0] = __fmul_rn(r0, a.aux_dx_scale);
+    a.gg_out[(size_t)c.pt * 3 + 1] = __fmul_rn(r1, a.aux_dx_scale);
+    a.gg_out[(size_t)c.pt * 3 + 2] = __fmul_rn(r2, a.aux_dx_scale);
+  }
   const int in0_tiles = plan.e_tiles + plan.aux_tiles;
 
   v4f in[MT], acc[MT];

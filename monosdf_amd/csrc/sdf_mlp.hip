@@ -165,6 +165,7 @@ extern "C" int msdf_sdf_fwd_grad(const msdf_plan_t* plan, const msdf_fg_args_t* 
   if (a->P_pad < a->P || (a->P_pad % MLP_PTS_PER_WG) != 0) return MSDF_ERR_ARG;
   if (plan->aux_tiles > 0 && a->aux == nullptr) return MSDF_ERR_ARG;
   if (!aux_layout_ok(plan, a->aux_C, a->aux_LC)) return MSDF_ERR_ARG;
+  if (a->dy_dx != nullptr && (a->aux_C != 2 || a->r_aux == nullptr)) return MSDF_ERR_ARG;
   if (plan->precision == MSDF_PRECISION_BF16X3 || plan->precision == MSDF_PRECISION_BF16X6) return msdf_b16_sdf_fwd_grad(plan, a, (hipStream_t)stream);
   if (mlp_prepare((const void*)msdf_sdf_fwd_grad_k)) return MSDF_ERR_LAUNCH;
   msdf_sdf_fwd_grad_k<<<a->P_pad / MLP_PTS_PER_WG, MLP_THREADS, MLP_LDS_BYTES, (hipStream_t)stream>>>(*plan, *a);
@@ -176,6 +177,7 @@ extern "C" int msdf_sdf_backward(const msdf_plan_t* plan, const msdf_bw_args_t* 
   if (a->P == 0) return MSDF_OK;
   if (a->P_pad < a->P || (a->P_pad % MLP_PTS_PER_WG) != 0) return MSDF_ERR_ARG;
   if (!aux_layout_ok(plan, a->aux_C, a->aux_LC)) return MSDF_ERR_ARG;
+  if (a->dy_dx != nullptr && a->aux_C != 2) return MSDF_ERR_ARG;
   if (plan->precision == MSDF_PRECISION_BF16X3 || plan->precision == MSDF_PRECISION_BF16X6) return msdf_b16_sdf_backward(plan, a, (hipStream_t)stream);
   if (mlp_prepare((const void*)msdf_sdf_backward_k)) return MSDF_ERR_LAUNCH;
   msdf_sdf_backward_k<<<a->P_pad / MLP_PTS_PER_WG, MLP_THREADS, MLP_LDS_BYTES, (hipStream_t)stream>>>(*plan, *a);

@@ -46,6 +46,9 @@ _DEFERRED = []         # launches queued for the side stream: callables
 _PENDING = []          # events of side-stream work whose results the main stream has not waited for yet
 USE_SIDE_STREAM = _os.environ.get('MSDF_SIDE_STREAM', '1') != '0'
 COLOR_WGRAD_EARLY = _os.environ.get('MSDF_COLOR_WGRAD_EARLY', '1') != '0'
+# hash-grid node: the encoder's Jacobian applied inside the SDF kernels (0: msdf_hash_node_input_gradient /
+# msdf_hash_node_second_grad as launches of their own -- comparison runs)
+FUSE_JACOBIAN = _os.environ.get('MSDF_FUSE_JACOBIAN', '1') != '0'
 
 
 def _side_stream(device):
@@ -288,9 +291,12 @@ class SdfMlpFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, aux, flat_w, flat_b, wpack, bpack, mlp, n_clamp, n_feat, clamp_radius,
-                sphere_scale, save, n_split=None, aux_lm=None):
+                sphere_scale, save, n_split=None, aux_lm=None, aux_jac=None):
         """aux_lm = (C, L C): aux, d sdf / d aux (the last output) and -- in backward -- their gradients are the hash
-        encoder's level-major tensors [L, P, C] instead of rows [P, 16 * aux_tiles]."""
+        encoder's level-major tensors [L, P, C] instead of rows [P, 16 * aux_tiles].
+        aux_jac = (dy_dx, k) (with aux_lm, C = 2): the encoder's Jacobian [L, P, 3, 2] and the chain-rule factor of
+        x -> x01; the kernel then adds the grid part of d sdf / d x to the returned gradient itself, and the backward
+        kernel forms the gradient arriving at d sdf / d aux from it (ctx.gg_out, set by the caller, receives k * g_nrm)."""
         ctx.set_materialize_grads(False)
         mp = mlp.mp
         plan = mlp.plan
@@ -331,6 +337,10 @@ class SdfMlpFunction(torch.autograd.Function):
         a.IN0 = base + 4 * woff['IN0'] if save else None
         a.save = 1 if save else 0
         a.aux_C, a.aux_LC = int(aC), int(aLC)
+        ctx.aux_jac = None
+        if aux_jac is not None and aC == 2:
+            a.dy_dx, a.aux_dx_scale = aux_jac[0].data_ptr(), float(aux_jac[1])
+            ctx.aux_jac = (aux_jac[0], float(aux_jac[1]))
         if P > 0:
             _lib.call('msdf_sdf_fwd_grad', C.byref(plan), C.byref(a), _lib.stream_ptr())
         ctx.mlp, ctx.P, ctx.P_pad, ctx.n_feat, ctx.saved = mlp, P, P_pad, n_feat, save
@@ -356,6 +366,11 @@ class SdfMlpFunction(torch.autograd.Function):
         g_aux = torch.empty(*ctx.aux_shape, device=dev, dtype=torch.float32) if ctx.has_aux else None
         b = _lib.BwArgs()
         b.aux_C, b.aux_LC = ctx.aux_lm
+        jac = getattr(ctx, 'aux_jac', None)
+        if jac is not None:
+            gg_out = getattr(ctx, 'gg_out', None)
+            b.dy_dx, b.aux_dx_scale = jac[0].data_ptr(), jac[1]
+            b.gg_out = gg_out.data_ptr() if gg_out is not None else None
         b.wpack, b.bpack, b.x = wpack.data_ptr(), bpack.data_ptr(), x.data_ptr()
         b.P, b.P_pad, b.n_feat, b.n_split = P, P_pad, ctx.n_feat, ctx.n_split
         b.g_sdf_b = g_sdf_b.data_ptr() if g_sdf_b is not None else None
@@ -382,7 +397,7 @@ class SdfMlpFunction(torch.autograd.Function):
             if between is not None:
                 between(g_aux)
             grad = torch.zeros(mp.n_w + mp.n_b, device=dev)
-        return (None, g_aux, grad[:mp.n_w], grad[mp.n_w:], None, None, None, None, None, None, None, None, None, None)
+        return (None, g_aux, grad[:mp.n_w], grad[mp.n_w:]) + (None,) * 11
 
 
 class _InnerCtx:
@@ -437,15 +452,18 @@ class GridSdfFunction(torch.autograd.Function):
             aux = torch.empty(B, A, device=x.device, dtype=torch.float32)
             _lib.call('msdf_hash_transpose', _lib.ptr(outputs), _lib.ptr(aux), None, None, L, B, Cdim, A, 1, st)
         inner = _InnerCtx()
+        # d sdf / d x through the grid: sum_{l,c} (d sdf / d feature) * d feature / d x01, chain rule to x, added to the
+        # MLP's own d sdf / d x -- inside the SDF kernel with the level-major tensors (FUSE_JACOBIAN), otherwise by
+        # msdf_hash_node_input_gradient in place (nrm_a / nrm_b are the two halves of ONE [B,3] buffer starting at nrm_a)
+        k = 0.5 / divide_factor
+        jac = (dy_dx, k) if (lm is not None and FUSE_JACOBIAN) else None
         # the grid class never clamps (network.py:290-309): clamp radius 0
         sdf_a, sdf_b, feat, nrm_a, nrm_b, r_aux = SdfMlpFunction.forward(
-            inner, x, aux, flat_w, flat_b, wpack, bpack, mlp, n_clamp, n_feat, 0.0, sphere_scale, save, n_split, lm)
-        # d sdf / d x through the grid: sum_{l,c} (d sdf / d feature) * d feature / d x01, chain rule to x, added to the
-        # MLP's own d sdf / d x in place (nrm_a / nrm_b are the two halves of ONE [B,3] buffer starting at nrm_a)
-        k = 0.5 / divide_factor
-        assert nrm_a.data_ptr() + 12 * nrm_a.shape[0] == nrm_b.data_ptr() or nrm_b.shape[0] == 0
-        _lib.call('msdf_hash_node_input_gradient', _lib.ptr(r_aux), 0 if lm is not None else A, _lib.ptr(dy_dx), B, Cdim,
-                  L, float(k), _lib.ptr(nrm_a), st)
+            inner, x, aux, flat_w, flat_b, wpack, bpack, mlp, n_clamp, n_feat, 0.0, sphere_scale, save, n_split, lm, jac)
+        if jac is None:
+            assert nrm_a.data_ptr() + 12 * nrm_a.shape[0] == nrm_b.data_ptr() or nrm_b.shape[0] == 0
+            _lib.call('msdf_hash_node_input_gradient', _lib.ptr(r_aux), 0 if lm is not None else A, _lib.ptr(dy_dx), B,
+                      Cdim, L, float(k), _lib.ptr(nrm_a), st)
         ctx.inner, ctx.enc, ctx.k, ctx.n_entries, ctx.lm = inner, enc, k, emb.shape[0], lm
         ctx.offsets = offsets
         ctx.save_for_backward(x01, dy_dx, r_aux, *inner.saved_tensors)
@@ -468,12 +486,17 @@ class GridSdfFunction(torch.autograd.Function):
         # one launch, written as the rows the SDF backward kernel reads
         lm = ctx.lm
         gg = torch.empty(B, D, device=dev, dtype=torch.float32)
-        g_raux = torch.empty(*((L, B, Cdim) if lm is not None else (B, A)), device=dev, dtype=torch.float32)
-        cont = lambda t: None if t is None else t.contiguous()
-        g_nrm_c, g_nrm_b_c = cont(g_nrm), cont(g_nrm_b)
-        _lib.call('msdf_hash_node_second_grad', _lib.ptr(g_nrm_c) if g_nrm_c is not None else None,
-                  _lib.ptr(g_nrm_b_c) if g_nrm_b_c is not None else None, ns, float(k), _lib.ptr(gg), _lib.ptr(dy_dx),
-                  _lib.ptr(g_raux), 0 if lm is not None else A, B, Cdim, L, st)
+        if getattr(inner, 'aux_jac', None) is not None:
+            # the SDF backward kernel forms this gradient from dy_dx itself and writes gg (k * g_nrm) for the scatter
+            g_raux = None
+            inner.gg_out = gg
+        else:
+            g_raux = torch.empty(*((L, B, Cdim) if lm is not None else (B, A)), device=dev, dtype=torch.float32)
+            cont = lambda t: None if t is None else t.contiguous()
+            g_nrm_c, g_nrm_b_c = cont(g_nrm), cont(g_nrm_b)
+            _lib.call('msdf_hash_node_second_grad', _lib.ptr(g_nrm_c) if g_nrm_c is not None else None,
+                      _lib.ptr(g_nrm_b_c) if g_nrm_b_c is not None else None, ns, float(k), _lib.ptr(gg), _lib.ptr(dy_dx),
+                      _lib.ptr(g_raux), 0 if lm is not None else A, B, Cdim, L, st)
         done = []
 
         def scatter(g_aux):
@@ -504,6 +527,7 @@ class GridSdfFunction(torch.autograd.Function):
         finally:
             inner.after_sweeps = None
             inner.saved_tensors = ()
+            inner.gg_out = None
         g_w, g_b = res[2], res[3]
         # the only reference to the table gradient leaves with the return value: autograd then adopts the tensor as
         # embeddings.grad instead of copying 48.8 MB

@@ -420,7 +420,15 @@ def choose_splits(classes, n_stages, part_floats, target_us=None):
     best = None
     # workgroups longer than ~500 us are outside what the model was fitted on (and measured 10-20 % slower than it says:
     # the narrow classes are latency-bound when they run beside wide workgroups instead of beside each other)
-    for D in (np.geomspace(100.0, 500.0, 80) if target_us is None else [float(target_us)]):
+    tau_top, t0_top = cost[top]
+    if target_us is None:
+        # every split count of the widest class whose workgroups last 100 ... 500 us, each with its own duration as D
+        s_lo = max(1, math.ceil(n_stages * tau_top / (500.0 - t0_top)))
+        s_hi = min(n_stages, max(s_lo, math.ceil(n_stages * tau_top / (100.0 - t0_top))))
+        cands = sorted({t0_top + tau_top * -(-n_stages // sw) for sw in range(s_lo, s_hi + 1)})
+    else:
+        cands = [float(target_us)]
+    for D in cands:
         S, part = {}, 0.0
         for c, n_items in classes.items():
             tau, t0 = cost[c]
