@@ -13,7 +13,8 @@ import sys
 def trace(path, kernel):
     lines = open(path).read().split('\n')
     start = next(i for i, l in enumerate(lines) if re.match(r'^_Z\d+%s\w*:' % kernel, l))
-    end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith('s_endpgm'))
+    # the function's end label, not its first s_endpgm: an early return (a skipped sampler round) may be laid out first
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith('.Lfunc_end'))
     out, last, cnt = [], None, 0
     for l in lines[start:end]:
         s = l.strip()
