@@ -360,6 +360,12 @@ struct CoreF32 {
   // it: the forward + gradient kernel spilled 208 bytes per lane with 17 bias tiles live beside two activation vectors,
   // 36 now (2.155 -> 2.08 ms, same box), the colour forward kernel 0.339 -> 0.332 ms
   static constexpr bool BIAS_IN_HOOKS = true;
+  // hash-grid features and their gradients as the encoder's level-major tensors, the encoder's Jacobian applied in the
+  // kernels (sdf_kernels.h: AuxView)
+#ifndef MLP_F32_AUX_LEVEL_MAJOR
+#define MLP_F32_AUX_LEVEL_MAJOR true     // timing experiments build a variant with false (rows + transposes, round 3's kernels)
+#endif
+  static constexpr bool AUX_LEVEL_MAJOR = MLP_F32_AUX_LEVEL_MAJOR;
   static __device__ __forceinline__ float softplus(const float a) {
     float h, s;
     softplus100(a, h, s);

@@ -258,6 +258,7 @@ struct CoreB16N {
   // three planes only: the two-plane core keeps its accumulators starting from the bias (its results, and the rows of
   // the tolerance table measured on them, stay as they are; it gains 1 % from the change, the three-plane core 10 %)
   static constexpr bool BIAS_IN_HOOKS = (NS == 3);
+  static constexpr bool AUX_LEVEL_MAJOR = false;      // rows + transposes: these kernels have no registers to spare
   // two planes: the lean softplus (its differences are far below that core's product error); three planes carry
   // fp32-grade products, so the activation is the fp32 core's
   static __device__ __forceinline__ float softplus(const float a) {

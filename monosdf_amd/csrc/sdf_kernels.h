@@ -40,10 +40,13 @@ struct AuxView {
 };
 typedef float v2f_aux __attribute__((ext_vector_type(2)));
 
+// LM = false compiles the level-major form out (the bf16 cores: their kernels sit at the register limit and the extra
+// address arithmetic cost them 30-100 bytes of scratch per lane; they take rows and the LDS-tiled transposes)
+template <bool LM>
 __device__ __forceinline__ v4f aux_load_tile(const float* __restrict__ base, const AuxView av, const int aux_tiles,
                                              const int t, const int pt, const int q) {
   const int s0 = 16 * t + 4 * q;
-  if (av.C == 0) return *(const v4f*)(base + (size_t)pt * (16 * aux_tiles) + s0);
+  if (!LM || av.C == 0) return *(const v4f*)(base + (size_t)pt * (16 * aux_tiles) + s0);
   // C == 2: levels s0 / 2 and s0 / 2 + 1 (LC is even: both inside or both outside)
   const int l = (s0 < av.LC) ? (s0 >> 1) : 0;
   const v2f_aux a = *(const v2f_aux*)(base + ((size_t)l * av.P + pt) * 2);
@@ -54,10 +57,11 @@ __device__ __forceinline__ v4f aux_load_tile(const float* __restrict__ base, con
   return v;
 }
 
+template <bool LM>
 __device__ __forceinline__ void aux_store_tile(float* __restrict__ base, const AuxView av, const int aux_tiles,
                                                const int t, const int pt, const int q, const v4f v) {
   const int s0 = 16 * t + 4 * q;
-  if (av.C == 0) { *(v4f*)(base + (size_t)pt * (16 * aux_tiles) + s0) = v; return; }
+  if (!LM || av.C == 0) { *(v4f*)(base + (size_t)pt * (16 * aux_tiles) + s0) = v; return; }
   if (s0 >= av.LC) return;
   const int l = s0 >> 1;
   *(v2f_aux*)(base + ((size_t)l * av.P + pt) * 2) = (v2f_aux){v.x, v.y};
@@ -109,6 +113,7 @@ __device__ __forceinline__ v4f aux_jacobian_tile(const float* __restrict__ dy_dx
 }
 
 // network input tiles: PE tiles then aux tiles (hash-grid features)
+template <bool LM>
 __device__ __forceinline__ void load_input_tiles(v4f (&in0)[5], const msdf_plan_t& plan,
                                                  const float* __restrict__ aux, const AuxView av, const PointCtx& c) {
   pe_values(in0, c.x0, c.x1, c.x2, plan.n_freqs);
@@ -116,7 +121,7 @@ __device__ __forceinline__ void load_input_tiles(v4f (&in0)[5], const msdf_plan_
   if (plan.aux_tiles > 0) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
-      if (t < plan.aux_tiles) in0[3 + t] = aux_load_tile(aux, av, plan.aux_tiles, t, c.ptc, c.q);
+      if (t < plan.aux_tiles) in0[3 + t] = aux_load_tile<LM>(aux, av, plan.aux_tiles, t, c.ptc, c.q);
   }
 }
 
@@ -305,7 +310,7 @@ __device__ __forceinline__ void sdf_forward_body(const msdf_plan_t& plan, const 
   const int in0_tiles = plan.e_tiles + plan.aux_tiles;
   {
     v4f in0[5];
-    load_input_tiles(in0, plan, aux, av, c);
+    load_input_tiles<Core::AUX_LEVEL_MAJOR>(in0, plan, aux, av, c);
     place_tiles(in, 0, in0, in0_tiles);
   }
   const int nl = plan.n_layers;
@@ -314,7 +319,7 @@ __device__ __forceinline__ void sdf_forward_body(const msdf_plan_t& plan, const 
     // skip layer: the network input is appended after the hidden tiles (1/sqrt2 folded into the pack)
     if (L.skip_tile >= 0) {
       v4f in0[5];
-      load_input_tiles(in0, plan, aux, av, c);
+      load_input_tiles<Core::AUX_LEVEL_MAJOR>(in0, plan, aux, av, c);
       place_tiles(in, L.skip_tile, in0, in0_tiles);
     }
     if constexpr (Core::BIAS_IN_HOOKS) {
@@ -351,7 +356,7 @@ __device__ __forceinline__ void sdf_fwd_grad_body(const msdf_plan_t& plan, const
   const size_t Pp = (size_t)a.P_pad;
   {
     v4f in0[5];
-    load_input_tiles(in0, plan, a.aux, av, c);
+    load_input_tiles<Core::AUX_LEVEL_MAJOR>(in0, plan, a.aux, av, c);
     place_tiles(in, 0, in0, in0_tiles);
     if (a.save) {
 #pragma unroll
@@ -367,7 +372,7 @@ __device__ __forceinline__ void sdf_fwd_grad_body(const msdf_plan_t& plan, const
     const msdf_layer_t L = plan.layer[l];
     if (L.skip_tile >= 0) {
       v4f in0[5];
-      load_input_tiles(in0, plan, a.aux, av, c);
+      load_input_tiles<Core::AUX_LEVEL_MAJOR>(in0, plan, a.aux, av, c);
       place_tiles(in, L.skip_tile, in0, in0_tiles);
     }
     float* Hl = a.H + (size_t)L.hpre * Pp + (size_t)c.pt * (16 * L.ot) + 4 * c.q;
@@ -463,7 +468,7 @@ __device__ __forceinline__ void sdf_fwd_grad_body(const msdf_plan_t& plan, const
   }
   // d sdf / d x through the hash grid (its chain-rule factor a.aux_dx_scale in), added as the module's tensor
   // expression adds it: the rounded product, then the sum
-  if (a.dy_dx != nullptr && plan.aux_tiles > 0) {
+  if (Core::AUX_LEVEL_MAJOR && a.dy_dx != nullptr && plan.aux_tiles > 0) {
     float m0, m1, m2;
     aux_jacobian_transpose(a.dy_dx, av, plan.aux_tiles, r_aux, c.ptc, c.q, m0, m1, m2);
     n0 = __fadd_rn(n0, __fmul_rn(sum_over_quarters(m0), a.aux_dx_scale));
@@ -496,7 +501,7 @@ __device__ __forceinline__ void sdf_fwd_grad_body(const msdf_plan_t& plan, const
         if (t < plan.aux_tiles) {
           v4f v = r_aux[t];
           if (is_clamped) v = V4ZERO;
-          aux_store_tile(a.r_aux, av, plan.aux_tiles, t, c.pt, c.q, v);
+          aux_store_tile<Core::AUX_LEVEL_MAJOR>(a.r_aux, av, plan.aux_tiles, t, c.pt, c.q, v);
         }
     }
   }
@@ -510,12 +515,13 @@ __device__ __forceinline__ void sdf_fwd_grad_body(const msdf_plan_t& plan, const
 // ---------------------------------------------------------------------------
 typedef msdf_bw_args_t BwArgs;
 
+template <bool LM>
 __device__ __forceinline__ void load_rbar(v4f (&rbar)[5], const msdf_plan_t& plan, const BwArgs& a,
                                           const PointCtx& c, const bool live, const float gn0, const float gn1,
                                           const float gn2) {
   pe_jacobian(rbar, c.x0, c.x1, c.x2, plan.n_freqs, gn0, gn1, gn2);
   rbar[3] = rbar[4] = V4ZERO;
-  if (a.dy_dx != nullptr && live) {
+  if (LM && a.dy_dx != nullptr && live) {
     // formed here from the encoder's Jacobian instead of read from a tensor a kernel of its own wrote
     const AuxView av = {a.aux_C, a.aux_LC, a.P};
     const float g0 = __fmul_rn(gn0, a.aux_dx_scale), g1 = __fmul_rn(gn1, a.aux_dx_scale), g2 = __fmul_rn(gn2, a.aux_dx_scale);
@@ -526,7 +532,7 @@ __device__ __forceinline__ void load_rbar(v4f (&rbar)[5], const msdf_plan_t& pla
     const AuxView av = {a.aux_C, a.aux_LC, a.P};
 #pragma unroll
     for (int t = 0; t < 2; ++t)
-      if (t < plan.aux_tiles) rbar[3 + t] = aux_load_tile(a.g_raux, av, plan.aux_tiles, t, c.pt, c.q);
+      if (t < plan.aux_tiles) rbar[3 + t] = aux_load_tile<LM>(a.g_raux, av, plan.aux_tiles, t, c.pt, c.q);
   }
 }
 
@@ -552,7 +558,7 @@ __device__ __forceinline__ void sdf_backward_body(const msdf_plan_t& plan, const
     }
   }
   if (c.q == 0) a.GSDF[c.pt] = gs;
-  if (a.gg_out != nullptr && c.valid && c.q == 0) {
+  if (Core::AUX_LEVEL_MAJOR && a.gg_out != nullptr && c.valid && c.q == 0) {
     // the scaled gradient of d sdf / d x, which the embedding scatter's second-order term reads per point (also for
     // clamped points, as hg_node_second_grad_kernel writes it: their d sdf / d features is zero, so nothing comes of it)
     float r0 = 0.f, r1 = 0.f, r2 = 0.f;
@@ -571,7 +577,7 @@ __device__ __forceinline__ void sdf_backward_body(const msdf_plan_t& plan, const
   v4f in[MT], acc[MT];
   {
     v4f rbar[5];
-    load_rbar(rbar, plan, a, c, live, gn0, gn1, gn2);
+    load_rbar<Core::AUX_LEVEL_MAJOR>(rbar, plan, a, c, live, gn0, gn1, gn2);
     place_tiles(in, 0, rbar, in0_tiles);
   }
 
@@ -580,7 +586,7 @@ __device__ __forceinline__ void sdf_backward_body(const msdf_plan_t& plan, const
     const msdf_layer_t L = plan.layer[l];
     if (L.skip_tile >= 0) {
       v4f rbar[5];
-      load_rbar(rbar, plan, a, c, live, gn0, gn1, gn2);
+      load_rbar<Core::AUX_LEVEL_MAJOR>(rbar, plan, a, c, live, gn0, gn1, gn2);
       place_tiles(in, L.skip_tile, rbar, in0_tiles);
     }
     float* Ql = a.QB + (size_t)L.qpre * Pp + (size_t)c.pt * (16 * L.kt) + 4 * c.q;
@@ -658,7 +664,7 @@ __device__ __forceinline__ void sdf_backward_body(const msdf_plan_t& plan, const
     const AuxView av = {a.aux_C, a.aux_LC, a.P};
 #pragma unroll
     for (int t = 0; t < 2; ++t)
-      if (t < plan.aux_tiles) aux_store_tile(a.g_aux, av, plan.aux_tiles, t, c.pt, c.q, g_in_aux[t]);
+      if (t < plan.aux_tiles) aux_store_tile<Core::AUX_LEVEL_MAJOR>(a.g_aux, av, plan.aux_tiles, t, c.pt, c.q, g_in_aux[t]);
   }
 }
 

@@ -118,6 +118,7 @@ int msdf_b16_pack_weights(const msdf_plan_t* plan, const msdf_packrule_t* rules_
 int msdf_b16_sdf_forward(const msdf_plan_t* plan, const void* wpack, const float* bpack, const float* x,
                          const float* aux, int aux_C, int aux_LC, int P, float clamp_radius, float sphere_scale,
                          float* sdf, const uint32_t* run_flag, hipStream_t stream) {
+  if (aux_C != 0) return MSDF_ERR_UNSUPPORTED;
   const int grid = (P + B16_PTS_PER_WG - 1) / B16_PTS_PER_WG;
   const AuxView av = {aux_C, aux_LC, P};
   B16_PLANES(plan, {
@@ -129,6 +130,7 @@ int msdf_b16_sdf_forward(const msdf_plan_t* plan, const void* wpack, const float
 }
 
 int msdf_b16_sdf_fwd_grad(const msdf_plan_t* plan, const msdf_fg_args_t* a, hipStream_t stream) {
+  if (a->aux_C != 0 || a->dy_dx != nullptr) return MSDF_ERR_UNSUPPORTED;     // the bf16 cores take rows
   B16_PLANES(plan, {
     if (b16_prepare<NS>((const void*)msdf_sdf_fwd_grad_b16_k<NS>)) return MSDF_ERR_LAUNCH;
     msdf_sdf_fwd_grad_b16_k<NS><<<a->P_pad / B16_PTS_PER_WG, B16_THREADS, B16Cfg<NS>::LDS_BYTES, stream>>>(*plan, *a);
@@ -137,6 +139,7 @@ int msdf_b16_sdf_fwd_grad(const msdf_plan_t* plan, const msdf_fg_args_t* a, hipS
 }
 
 int msdf_b16_sdf_backward(const msdf_plan_t* plan, const msdf_bw_args_t* a, hipStream_t stream) {
+  if (a->aux_C != 0 || a->dy_dx != nullptr) return MSDF_ERR_UNSUPPORTED;
   B16_PLANES(plan, {
     if (b16_prepare<NS>((const void*)msdf_sdf_backward_b16_k<NS>)) return MSDF_ERR_LAUNCH;
     msdf_sdf_backward_b16_k<NS><<<a->P_pad / B16_PTS_PER_WG, B16_THREADS, B16Cfg<NS>::LDS_BYTES, stream>>>(*plan, *a);

@@ -210,7 +210,8 @@ class _SdfBase(_FusedNet):
                 # x01 inside the encoder kernel; the SDF kernel reads the encoder's level-major output
                 aux, aux_lm = ops.hash_node_features(
                     x, self.divide_factor, enc.embeddings, enc.offsets,
-                    (enc.num_levels, enc.level_dim, enc.log2_scale, int(enc.base_resolution)), 16 * fused.plan.aux_tiles)
+                    (enc.num_levels, enc.level_dim, enc.log2_scale, int(enc.base_resolution)), 16 * fused.plan.aux_tiles,
+                    level_major=(fused.precision == 'fp32'))
             else:
                 with torch.no_grad():
                     aux = self._pad_aux(enc((x / self.divide_factor).detach(), calc_grad_inputs=False))

@@ -445,7 +445,7 @@ class GridSdfFunction(torch.autograd.Function):
                   _lib.ptr(offsets), _lib.ptr(outputs), 0, B, Cdim, L, S, H, _lib.ptr(dy_dx), st)
         # two features per level (every configuration of the reference): the SDF kernels read and write the encoder's
         # level-major tensors themselves; other channel counts go through rows and the LDS-tiled transpose
-        lm = (Cdim, L * Cdim) if Cdim == 2 else None
+        lm = (Cdim, L * Cdim) if (Cdim == 2 and mlp.precision == 'fp32') else None      # the bf16 cores take rows
         if lm is not None:
             aux = outputs
         else:
@@ -534,7 +534,7 @@ class GridSdfFunction(torch.autograd.Function):
         return (None, done.pop(), g_w, g_b) + (None,) * 10
 
 
-def hash_node_features(x, divide_factor, embeddings, offsets, enc, pitch):
+def hash_node_features(x, divide_factor, embeddings, offsets, enc, pitch, level_major=True):
     """Grid features of the points x (world coordinates), no gradient: what the sampler's SDF evaluations feed the fused
     forward kernel -- x01 inside the encoder kernel.  Returns (tensor, aux_lm): the encoder's level-major [L, B, C]
     tensor with aux_lm = (C, L C) for two features per level, else rows of `pitch` floats (one LDS-tiled transpose)
@@ -547,7 +547,7 @@ def hash_node_features(x, divide_factor, embeddings, offsets, enc, pitch):
     outputs = torch.empty(L, B, Cdim, device=x.device, dtype=torch.float32)
     _lib.call('msdf_hash_node_forward', _lib.ptr(x), float(divide_factor), None, _lib.ptr(emb), _lib.ptr(offsets),
               _lib.ptr(outputs), 0, B, Cdim, L, S, H, None, st)
-    if Cdim == 2:
+    if Cdim == 2 and level_major:
         return outputs, (Cdim, L * Cdim)          # the SDF kernel reads the level-major tensor itself
     aux = torch.empty(B, pitch, device=x.device, dtype=torch.float32)
     _lib.call('msdf_hash_transpose', _lib.ptr(outputs), _lib.ptr(aux), None, None, L, B, Cdim, pitch, 1, st)
