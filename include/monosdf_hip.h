@@ -265,7 +265,8 @@ int msdf_color_backward(const msdf_plan_t* plan, const msdf_color_bwd_args_t* ar
 
 /* wg_map_dev: int32 pairs (item, split) for each of the n_wgs workgroups (balanced by the host) */
 int msdf_wgrad(const msdf_wgrad_item_t* items_dev, const int32_t* wg_map_dev, int n_wgs, float* partials,
-               int P_pad, int precision /* MSDF_PRECISION_* */, void* stream);
+               int P_pad, int precision /* MSDF_PRECISION_* */, const float* base0, const float* base1 /* the items'
+               operand buffers; base1 may be NULL when no item names it */, void* stream);
 int msdf_reduce(const msdf_reduce_rule_t* rules_dev, int n_rules, const int* maps_dev, const float* partials,
                 float* dst, void* stream);
 

@@ -66,20 +66,22 @@ typedef struct {
 } msdf_packrule_t;
 
 /* one weight-gradient work item: PART[split] = sum_{p in split} X[p][0:wx]^T Y[p][0:wy]
- * (+ optional column sums of X, + optional sum_p v[p] Y[p][:]).  X / Y / v are device pointers (the operands of
- * one launch live in different buffers: the saved activations, the feature tensor); the *_off fields are float
- * offsets into the partial buffer. */
+ * (+ optional column sums of X, + optional sum_p v[p] Y[p][:]).  X / Y / v are float offsets into one of the launch's
+ * two operand buffers (msdf_wgrad: base0 = the saved activations, base1 = the feature tensor) -- the table holds no
+ * device address, so it is built once per network and point count and never copied again (a table of absolute
+ * addresses had to be re-sent, synchronously, whenever the allocator handed the step other blocks); the *_off fields
+ * below them are float offsets into the partial buffer. */
 typedef struct {
-  const float* x;               /* [P_pad, x_ld] */
-  const float* y;               /* [P_pad, y_ld] */
-  const float* v;               /* [P_pad] or NULL */
+  int64_t x;                    /* float offset of X [P_pad, x_ld] in its buffer */
+  int64_t y;                    /* float offset of Y [P_pad, y_ld] */
+  int64_t v;                    /* float offset of v [P_pad] (bufs: no v when its byte is 0xff) */
   int64_t part_off;             /* [n_splits][wx*wy] */
   int64_t colsum_off;           /* [n_splits][wx] or < 0 */
   int64_t vrow_off;             /* [n_splits][wy] or < 0 */
   int32_t x_ld, y_ld;           /* row pitches of X and Y */
   int32_t wx, wy;               /* multiples of 16, <= 256; wy == 0: column sums only */
   int32_t n_splits;             /* this item's share of the points is cut into n_splits workgroups */
-  int32_t pad_;
+  int32_t bufs;                 /* buffer index (0 / 1) of x | y << 8 | v << 16 (0xff: none) */
 } msdf_wgrad_item_t;
 
 /* one reduction rule: dst[rowmap[i]*dst_ld + colmap[j]] = scale * sum_b PART[b][i*wy + j] */

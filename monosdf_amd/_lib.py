@@ -33,10 +33,10 @@ class PackRule(C.Structure):
 
 
 class WgradItem(C.Structure):
-    _fields_ = [('x', C.c_void_p), ('y', C.c_void_p), ('v', C.c_void_p),
+    _fields_ = [('x', C.c_int64), ('y', C.c_int64), ('v', C.c_int64),
                 ('part_off', C.c_int64), ('colsum_off', C.c_int64), ('vrow_off', C.c_int64),
                 ('x_ld', C.c_int32), ('y_ld', C.c_int32), ('wx', C.c_int32), ('wy', C.c_int32),
-                ('n_splits', C.c_int32), ('pad_', C.c_int32)]
+                ('n_splits', C.c_int32), ('bufs', C.c_int32)]
 
 
 class ReduceRule(C.Structure):
@@ -170,7 +170,7 @@ _SIGNATURES = {
     'msdf_sdf_backward': [C.POINTER(Plan), C.POINTER(BwArgs), _P],
     'msdf_color_forward': [C.POINTER(Plan), C.POINTER(ColorFwdArgs), _P],
     'msdf_color_backward': [C.POINTER(Plan), C.POINTER(ColorBwdArgs), _P],
-    'msdf_wgrad': [_P, _P, C.c_int, _P, C.c_int, C.c_int, _P],
+    'msdf_wgrad': [_P, _P, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P],
     'msdf_camera_rays': [_P, _P, _P, C.c_int, _P, _P, _P, _P],
     'msdf_monosdf_loss': [C.POINTER(MonoSdfLossArgs), _P],
     'msdf_reduce': [_P, C.c_int, _P, _P, _P, _P],

@@ -70,7 +70,8 @@ __device__ __forceinline__ void wg_wait_outstanding(const int stages_behind) {
 // NBN == -1: items of <= 32 rows, 1 x 8 waves of 32 rows x 32 columns.
 template <int NBN>
 __device__ __forceinline__ void wgrad_body(const msdf_wgrad_item_t& it, const int split,
-                                           float* __restrict__ part, const int P_pad, float* lds_f) {
+                                           float* __restrict__ part, const int P_pad, float* lds_f,
+                                           const float* __restrict__ base0, const float* __restrict__ base1) {
   const int n_splits = it.n_splits;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -92,9 +93,9 @@ __device__ __forceinline__ void wgrad_body(const msdf_wgrad_item_t& it, const in
   const int s_end = min(n_stages_total, s_begin + per);
   const int n_st = max(0, s_end - s_begin);
 
-  const float* X = it.x;
-  const float* Y = it.y;
-  const float* V = it.v;
+  const float* X = ((it.bufs & 0xff) ? base1 : base0) + it.x;
+  const float* Y = (((it.bufs >> 8) & 0xff) ? base1 : base0) + it.y;
+  const float* V = (((it.bufs >> 16) & 0xff) == 0xff) ? nullptr : ((((it.bufs >> 16) & 0xff) ? base1 : base0) + it.v);
   const bool do_mm = it.wy > 0;
 
   v16f acc[na][nb];
@@ -202,16 +203,17 @@ __device__ __forceinline__ void wgrad_body(const msdf_wgrad_item_t& it, const in
 
 __global__ void __launch_bounds__(WG_THREADS, 2)
 msdf_wgrad_k(const msdf_wgrad_item_t* __restrict__ items, const int* __restrict__ wg_map,
-             float* __restrict__ part, const int P_pad) {
+             float* __restrict__ part, const int P_pad, const float* __restrict__ base0,
+             const float* __restrict__ base1) {
   extern __shared__ float lds_f[];
   const msdf_wgrad_item_t it = items[wg_map[2 * blockIdx.x]];
   const int split = wg_map[2 * blockIdx.x + 1];
   // wide items: 2 x 4 waves of 128 x 64; items of <= 128 columns: 8 x 1 waves of 32 x (64 | 96 | 128)
-  if (it.wx <= 32 && it.wy > 32) wgrad_body<-1>(it, split, part, P_pad, lds_f);
-  else if (it.wy <= 64) wgrad_body<2>(it, split, part, P_pad, lds_f);
-  else if (it.wy <= 96) wgrad_body<3>(it, split, part, P_pad, lds_f);
-  else if (it.wy <= 128) wgrad_body<4>(it, split, part, P_pad, lds_f);
-  else wgrad_body<0>(it, split, part, P_pad, lds_f);
+  if (it.wx <= 32 && it.wy > 32) wgrad_body<-1>(it, split, part, P_pad, lds_f, base0, base1);
+  else if (it.wy <= 64) wgrad_body<2>(it, split, part, P_pad, lds_f, base0, base1);
+  else if (it.wy <= 96) wgrad_body<3>(it, split, part, P_pad, lds_f, base0, base1);
+  else if (it.wy <= 128) wgrad_body<4>(it, split, part, P_pad, lds_f, base0, base1);
+  else wgrad_body<0>(it, split, part, P_pad, lds_f, base0, base1);
 }
 
 
@@ -246,7 +248,8 @@ __device__ __forceinline__ void wb_split8(const float (&v)[8], wv8bf& hi, wv8bf&
 template <bool NARROW>
 __device__ __forceinline__ void wgrad_b16_body(const msdf_wgrad_item_t& it, const int split,
                                                float* __restrict__ part,
-                                               const int P_pad, wv8bf* lds_img) {
+                                               const int P_pad, wv8bf* lds_img,
+                                               const float* __restrict__ base0, const float* __restrict__ base1) {
   const int n_splits = it.n_splits;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -263,9 +266,9 @@ __device__ __forceinline__ void wgrad_b16_body(const msdf_wgrad_item_t& it, cons
   const int s_end = min(n_stages_total, s_begin + per);
   const int n_st = max(0, s_end - s_begin);
 
-  const float* X = it.x;
-  const float* Y = it.y;
-  const float* V = it.v;
+  const float* X = ((it.bufs & 0xff) ? base1 : base0) + it.x;
+  const float* Y = (((it.bufs >> 8) & 0xff) ? base1 : base0) + it.y;
+  const float* V = (((it.bufs >> 16) & 0xff) == 0xff) ? nullptr : ((((it.bufs >> 16) & 0xff) ? base1 : base0) + it.v);
   const bool do_mm = it.wy > 0;
   const bool want_vrow = it.vrow_off >= 0;
 
@@ -394,12 +397,13 @@ __device__ __forceinline__ void wgrad_b16_body(const msdf_wgrad_item_t& it, cons
 
 __global__ void __launch_bounds__(WG_THREADS, 2)
 msdf_wgrad_b16_k(const msdf_wgrad_item_t* __restrict__ items, const int* __restrict__ wg_map,
-                 float* __restrict__ part, const int P_pad) {
+                 float* __restrict__ part, const int P_pad, const float* __restrict__ base0,
+                 const float* __restrict__ base1) {
   extern __shared__ wv8bf lds_img[];
   const msdf_wgrad_item_t it = items[wg_map[2 * blockIdx.x]];
   const int split = wg_map[2 * blockIdx.x + 1];
-  if (it.wy <= 64) wgrad_b16_body<true>(it, split, part, P_pad, lds_img);
-  else wgrad_b16_body<false>(it, split, part, P_pad, lds_img);
+  if (it.wy <= 64) wgrad_b16_body<true>(it, split, part, P_pad, lds_img, base0, base1);
+  else wgrad_b16_body<false>(it, split, part, P_pad, lds_img, base0, base1);
 }
 
 
@@ -430,15 +434,17 @@ msdf_reduce_k(const msdf_reduce_rule_t* __restrict__ rules, const int* __restric
 }
 
 extern "C" int msdf_wgrad(const msdf_wgrad_item_t* items_dev, const int32_t* wg_map_dev, int n_wgs,
-                          float* partials, int P_pad, int precision, void* stream) {
+                          float* partials, int P_pad, int precision, const float* base0, const float* base1,
+                          void* stream) {
   if (n_wgs < 0 || P_pad < 0 || (P_pad % WB_NP) != 0) return MSDF_ERR_ARG;
+  if (n_wgs > 0 && P_pad > 0 && base0 == nullptr) return MSDF_ERR_ARG;
   if (n_wgs == 0 || P_pad == 0) return MSDF_OK;
   if (precision == MSDF_PRECISION_BF16X3) {
     if (hipFuncSetAttribute((const void*)msdf_wgrad_b16_k, hipFuncAttributeMaxDynamicSharedMemorySize,
                             WB_LDS_BYTES) != hipSuccess)
       return MSDF_ERR_LAUNCH;
     msdf_wgrad_b16_k<<<n_wgs, WG_THREADS, WB_LDS_BYTES, (hipStream_t)stream>>>(items_dev, wg_map_dev, partials,
-                                                                               P_pad);
+                                                                               P_pad, base0, base1);
     return msdf_check_launch();
   }
   // BF16X6 networks take the fp32 kernel: both operands are saved fp32 activations, a three-plane image of a stage
@@ -448,7 +454,7 @@ extern "C" int msdf_wgrad(const msdf_wgrad_item_t* items_dev, const int32_t* wg_
       hipSuccess)
     return MSDF_ERR_LAUNCH;
   msdf_wgrad_k<<<n_wgs, WG_THREADS, WG_LDS_BYTES, (hipStream_t)stream>>>(items_dev, wg_map_dev, partials,
-                                                                          P_pad);
+                                                                          P_pad, base0, base1);
   return msdf_check_launch();
 }
 

@@ -125,9 +125,11 @@ class FusedMlp:
             prog = planlib.balanced_program(build, self.mp, P_pad)
             rules_dev = torch.from_numpy(prog.rules_bytes()).to(self.device)
             wg_map = torch.from_numpy(prog.wg_map()).to(self.device)
+            # the item table holds offsets, not addresses: one host-to-device copy per (network, point count), ever
+            items_dev = torch.from_numpy(prog.items_bytes()).to(self.device)
             # when the reduce rules store to every gradient element the flat buffer needs no zero fill
             full = prog.writes_every_element(self.mp.n_w + self.mp.n_b, self.mp.maps_np)
-            self._wgrad_cache[key] = dict(prog=prog, rules=rules_dev, wg_map=wg_map, items={}, full=full)
+            self._wgrad_cache[key] = dict(prog=prog, rules=rules_dev, wg_map=wg_map, items=items_dev, full=full)
         return self._wgrad_cache[key]
 
     def run_wgrad(self, P_pad, base_addr, defer=False):
@@ -136,13 +138,8 @@ class FusedMlp:
         is filled by then."""
         ent = self.wgrad_program(P_pad)
         prog = ent['prog']
-        addr = {k: t.data_ptr() for k, t in base_addr.items()}
-        key = tuple(sorted(addr.items()))
-        if key not in ent['items']:
-            if len(ent['items']) > 8:
-                ent['items'].clear()
-            ent['items'][key] = torch.from_numpy(prog.items_bytes(addr)).to(self.device)
-        items_dev = ent['items'][key]
+        items_dev = ent['items']
+        bases = [base_addr.get(name) for name in prog.BUFFERS]
         part = torch.empty(prog.part_f + 64, device=self.device, dtype=torch.float32)
         alloc = torch.empty if ent['full'] else torch.zeros
         grad = alloc(self.mp.n_w + self.mp.n_b, device=self.device, dtype=torch.float32)
@@ -153,13 +150,12 @@ class FusedMlp:
 
         def launch(stream=None):
             if stream is not None:
-                # allocated on the main stream, used on this one: the work tables too (an evicted items table may
-                # otherwise return to the main stream's pool while the side stream still reads it)
+                # allocated on the main stream, used on this one
                 for t in held + [part, grad, items_dev, wg_map, rules_dev, self.maps_dev]:
                     t.record_stream(stream)
             st = _lib.stream_ptr()
             _lib.call('msdf_wgrad', _lib.ptr(items_dev), _lib.ptr(wg_map), wg_map.numel() // 2,
-                      _lib.ptr(part), P_pad, PRECISIONS.index(self.precision), st)
+                      _lib.ptr(part), P_pad, PRECISIONS.index(self.precision), _lib.ptr(bases[0]), _lib.ptr(bases[1]), st)
             _lib.call('msdf_reduce', _lib.ptr(rules_dev), len(prog.rules), _lib.ptr(self.maps_dev),
                       _lib.ptr(part), _lib.ptr(grad), st)
 

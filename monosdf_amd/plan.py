@@ -366,16 +366,19 @@ class WgradProgram:
         pairs = [(i, s) for i in order for s in range(self.items[i]['n_splits'])]
         return np.asarray(pairs, dtype=np.int32).reshape(-1)
 
-    def items_bytes(self, base_addr):
-        """base_addr: dict buffer name -> absolute device address (bytes)."""
+    BUFFERS = ('ws', 'feat')      # operand buffers of a launch, in the order msdf_wgrad takes their base pointers
+
+    def items_bytes(self):
+        """The work-item table (no device addresses in it: built once, msdf_wgrad takes the buffers' base pointers)."""
         out = []
+        buf = lambda ref: self.BUFFERS.index(ref[0])
         for it in self.items:
             w = _lib.WgradItem()
-            ax = base_addr[it['x'][0]]
-            w.x = ax + 4 * it['x'][1]
-            ay = base_addr[it['y'][0]] if it['y'] is not None else ax
-            w.y = ay + 4 * (it['y'][1] if it['y'] is not None else 0)
-            w.v = (base_addr[it['v'][0]] + 4 * it['v'][1]) if it['v'] is not None else None
+            bx = buf(it['x'])
+            w.x = it['x'][1]
+            by, w.y = (buf(it['y']), it['y'][1]) if it['y'] is not None else (bx, it['x'][1])
+            bv, w.v = (buf(it['v']), it['v'][1]) if it['v'] is not None else (0xff, 0)
+            w.bufs = bx | (by << 8) | (bv << 16)
             w.part_off, w.colsum_off, w.vrow_off = it['part_off'], it['colsum_off'], it['vrow_off']
             w.x_ld, w.y_ld, w.wx, w.wy = it['x_ld'], it['y_ld'], it['wx'], it['wy']
             w.n_splits = it['n_splits']

@@ -35,14 +35,14 @@ PREC = 0
 
 
 def run(prog, label, iters=10):
-    items = torch.from_numpy(prog.items_bytes({'ws': ws.data_ptr(), 'feat': feat.data_ptr()})).to(dev)
+    items = torch.from_numpy(prog.items_bytes()).to(dev)
     wg_map = torch.from_numpy(prog.wg_map()).to(dev)
     part = torch.empty(prog.part_f + 64, device=dev)
     st = _lib.stream_ptr()
     macs = sum(it['wx'] * it['wy'] for it in prog.items) * P_pad
 
     def once():
-        _lib.call('msdf_wgrad', _lib.ptr(items), _lib.ptr(wg_map), wg_map.numel() // 2, _lib.ptr(part), P_pad, PREC, st)
+        _lib.call('msdf_wgrad', _lib.ptr(items), _lib.ptr(wg_map), wg_map.numel() // 2, _lib.ptr(part), P_pad, PREC, _lib.ptr(ws), _lib.ptr(feat), st)
     once(); once(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -87,7 +87,7 @@ def calibrate():
     n_stages = P_pad // 32
     for S in (256, 512, 1024):
         prog = build(mp, P_pad, lambda w, S=S: S)
-        items = torch.from_numpy(prog.items_bytes({'ws': ws.data_ptr(), 'feat': feat.data_ptr()})).to(dev)
+        items = torch.from_numpy(prog.items_bytes()).to(dev)
         part = torch.empty(prog.part_f + 64, device=dev)
         for i, it in enumerate(prog.items):
             key = (it['wx'], it['wy'], it['colsum_off'] >= 0, it['vrow_off'] >= 0)
@@ -98,7 +98,7 @@ def calibrate():
             st = _lib.stream_ptr()
 
             def once():
-                _lib.call('msdf_wgrad', _lib.ptr(items), _lib.ptr(wg), S, _lib.ptr(part), P_pad, PREC, st)
+                _lib.call('msdf_wgrad', _lib.ptr(items), _lib.ptr(wg), S, _lib.ptr(part), P_pad, PREC, _lib.ptr(ws), _lib.ptr(feat), st)
             once(); once(); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

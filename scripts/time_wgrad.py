@@ -13,9 +13,9 @@ P_pad = 104448
 woff, total = planlib.sdf_workspace(mp, P_pad)
 ws = torch.randn(total, device=dev) * 0.01
 prog = planlib.build_sdf_wgrad(mp, P_pad, lambda w: S)
-items = torch.from_numpy(prog.items_bytes({'ws': ws.data_ptr()})).to(dev)
+items = torch.from_numpy(prog.items_bytes()).to(dev)
 wg_map = torch.from_numpy(prog.wg_map()).to(dev)
 part = torch.empty(prog.part_f + 64, device=dev)
 for _ in range(6):
-    _lib.call('msdf_wgrad', _lib.ptr(items), _lib.ptr(wg_map), wg_map.numel() // 2, _lib.ptr(part), P_pad, prec, _lib.stream_ptr())
+    _lib.call('msdf_wgrad', _lib.ptr(items), _lib.ptr(wg_map), wg_map.numel() // 2, _lib.ptr(part), P_pad, prec, _lib.ptr(ws), None, _lib.stream_ptr())
 torch.cuda.synchronize()
