@@ -27,6 +27,9 @@
  *   msdf_camera_rays
  *       rend_util.get_camera_params + lift, called twice per chunk (utils/rend_util.py:63-91, 105-118;
  *       model/network.py:505-516).
+ *   msdf_pixel_rays
+ *       the dataset's per-pixel ray tables and the pixel branch of its __getitem__ (datasets/scene_dataset.py:269-307,
+ *       374-401).
  *   msdf_monosdf_loss
  *       MonoSDFLoss.forward and its backward (model/loss.py:180-311 with 29-87, 156-171).
  *   msdf_probe_loss
@@ -436,6 +439,20 @@ int msdf_laplace_density_backward(const float* sdf, const float* beta, int beta_
  * (the reference's `ray_dirs_tmp`; its z is the depth scale), cam_loc [n,3] the camera centre per ray. */
 int msdf_camera_rays(const float* uv, const float* pose, const float* intrinsics, int n, float* ray_dirs,
                      float* ray_dirs_cam, float* cam_loc, void* stream);
+
+/* One pixel-mode training batch assembled on the device (second half; reference: the per-pixel tables of
+ * SceneDatasetDN.convert_to_pixels, datasets/scene_dataset.py:269-307, and the pixel branch of __getitem__ 374-401 with
+ * the DataLoader's collate + host-to-device copy).  ray_idx [n] int64 in [0, n_frames * hw): ray r is pixel
+ * (ray_idx[r] mod hw) of the frame at position ray_idx[r] / hw of frame_list [n_frames] (int32 indices into pose_all /
+ * intrinsics_all [N,4,4]; NULL = identity).  The pixel's (u, v) is (column, row) of a row-major image of `width` columns
+ * (scene_dataset.py:258-260).  Outputs: ray_dirs, ray_dirs_cam (the reference's ray_dirs_tmp), cam_loc [n,3],
+ * ray_pose [n,16], frame_pos [n] int32 (= ray_idx / hw, the reference's ray_frame_idx).  Ground truth: up to 4 image
+ * stacks gt_src[k] [n_frames * hw, gt_channels[k]] (rows in frame-list order, device pointers; the arrays of pointers
+ * themselves are HOST arrays) gathered into gt_dst[k] [n, gt_channels[k]]; a NULL gt_src[k] is skipped. */
+int msdf_pixel_rays(const int64_t* ray_idx, int n, const int32_t* frame_list, int n_frames, const float* pose_all,
+                    const float* intrinsics_all, int width, int hw, float* ray_dirs, float* ray_dirs_cam,
+                    float* cam_loc, float* ray_pose, int32_t* frame_pos, const float* const* gt_src,
+                    float* const* gt_dst, const int32_t* gt_channels, int n_gt, void* stream);
 
 #ifdef __cplusplus
 }

@@ -172,6 +172,7 @@ _SIGNATURES = {
     'msdf_color_backward': [C.POINTER(Plan), C.POINTER(ColorBwdArgs), _P],
     'msdf_wgrad': [_P, _P, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P],
     'msdf_camera_rays': [_P, _P, _P, C.c_int, _P, _P, _P, _P],
+    'msdf_pixel_rays': [_P, C.c_int, _P, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P],
     'msdf_monosdf_loss': [C.POINTER(MonoSdfLossArgs), _P],
     'msdf_reduce': [_P, C.c_int, _P, _P, _P, _P],
     'msdf_composite_forward': [C.POINTER(CompositeArgs), _P],

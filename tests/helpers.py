@@ -73,7 +73,7 @@ def rel_err(a, b):
 
 
 # full-forward cases (oracle/make_golden.py); the other fixtures have generators and tests of their own
-_OTHER = ('stages', 'loss_', 'volume_', 'traj_', 'plumbing_')
+_OTHER = ('stages', 'loss_', 'volume_', 'traj_', 'plumbing_', 'raytable_')
 ALL_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith('.npz') and not f.startswith(_OTHER))
 
 
