@@ -434,7 +434,9 @@ static int hg_launch_scatter(const float* grad, const float* inputs, const int* 
 // The sum order inside a bin follows the order in which workgroups reserved their runs: like the atomics it replaces
 // it is not fixed from run to run (differences at fp32 rounding).
 // ---------------------------------------------------------------------------
+#ifndef HB_SLICE_FLOATS
 #define HB_SLICE_FLOATS 8192
+#endif
 #define HB_CHUNK 8192
 #define HB_THREADS 256
 #define HB_PTS 4                      // points per thread in the count / place kernels (1,024 per workgroup)

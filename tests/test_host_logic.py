@@ -306,3 +306,46 @@ def test_grid_network_parameter_groups_as_the_runner_builds_them():
         for p in g['params']:
             step = (before[id(p)] - p.detach()).abs()
             assert torch.allclose(step, torch.full_like(step, g['lr']), rtol=1e-3, atol=1e-9), (g['name'], names.get(id(p)))
+
+
+@pytest.mark.parametrize('P_pad', [64, 640, 12800, 104448])
+def test_weight_gradient_split_plan_covers_every_point_once(P_pad):
+    """plan.choose_splits / balanced_program: whatever the point count, every item's point range is cut into >= 1
+    splits that together cover all 32-point stages, every (item, split) appears exactly once in the workgroup map,
+    workgroups are ordered longest first (the short ones fill the end of the launch), the item table holds no device
+    address (same bytes on every call) and the partial-sum blocks of the items do not overlap."""
+    import numpy as np
+    from monosdf_amd import plan as planlib
+    plans = [(planlib.build_sdf_plan([(256, 39), (256, 256), (256, 256), (217, 256), (256, 256), (256, 256), (256, 256),
+                                      (256, 256), (257, 256)], [4], 6, 0, False, 256), planlib.build_sdf_wgrad),
+             (planlib.build_sdf_plan([(256, 71), (256, 256), (257, 256)], [4], 6, 32, True, 256), planlib.build_sdf_wgrad),
+             (planlib.build_sdf_plan([(64, 39), (64, 64), (65, 64)], [], 6, 0, False, 64), planlib.build_sdf_wgrad),
+             (planlib.build_color_plan([(256, 289), (256, 256), (3, 256)], 'idr', 4, 256), planlib.build_color_wgrad)]
+    n_stages = P_pad // 32
+    for mp, build in plans:
+        prog = planlib.balanced_program(build, mp, P_pad)
+        assert prog.items
+        for it in prog.items:
+            assert 1 <= it['n_splits'] <= max(1, n_stages)
+            per = -(-n_stages // it['n_splits'])
+            assert per == it['stages_per_wg'] and per * it['n_splits'] >= n_stages
+        pairs = prog.wg_map().reshape(-1, 2)
+        want = {(i, s) for i, it in enumerate(prog.items) for s in range(it['n_splits'])}
+        assert len(pairs) == len(want) and {tuple(p) for p in pairs.tolist()} == want
+        durs = [prog.wg_duration_us(prog.items[i]) for i, _ in pairs.tolist()]
+        assert all(a >= b for a, b in zip(durs, durs[1:]))
+        assert np.array_equal(prog.items_bytes(), prog.items_bytes())
+        # partial blocks: [part_off, part_off + n_splits * wx * wy) and the column-sum / v-row blocks are disjoint
+        spans = []
+        for it in prog.items:
+            if it['wy'] > 0:
+                spans.append((it['part_off'], it['part_off'] + it['n_splits'] * it['wx'] * it['wy']))
+            if it['colsum_off'] >= 0:
+                spans.append((it['colsum_off'], it['colsum_off'] + it['n_splits'] * it['wx']))
+            if it['vrow_off'] >= 0:
+                spans.append((it['vrow_off'], it['vrow_off'] + it['n_splits'] * it['wy']))
+        spans.sort()
+        assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])) and spans[-1][1] <= prog.part_f
+        # the same plan every time (cached, deterministic): bitwise reproducible gradients depend on it
+        again = planlib.balanced_program(build, mp, P_pad)
+        assert [it['n_splits'] for it in again.items] == [it['n_splits'] for it in prog.items]
