@@ -432,7 +432,7 @@ class GridSdfFunction(torch.autograd.Function):
         offsets = mlp.grid_offsets
         A = 16 * mlp.plan.aux_tiles                 # row pitch of the grid features as the SDF kernels read them
         # the node forms of the hash kernels (csrc/hashgrid.hip): x01 formed inside the encoder kernel, which writes its
-        # own level-major [L, B, C] output; one LDS-tiled transpose turns it into the rows the SDF kernels read
+        # own level-major [L, B, C] output and the Jacobian dy_dx [L, B, 3, C]
         x01 = torch.empty(B, D, device=x.device, dtype=torch.float32)
         outputs = torch.empty(L, B, Cdim, device=x.device, dtype=torch.float32)
         dy_dx = torch.empty(B, L * D * Cdim, device=x.device, dtype=torch.float32)
