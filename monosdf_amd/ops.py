@@ -122,7 +122,13 @@ class FusedMlp:
         key = P_pad
         if key not in self._wgrad_cache:
             build = planlib.build_sdf_wgrad if self.mp.kind == 'sdf' else planlib.build_color_wgrad
-            prog = planlib.balanced_program(build, self.mp, P_pad)
+            # the split model is fitted to the fp32 kernel (also what the bf16x6 core runs); the bf16x3 kernel has its own
+            # stage times and wave grids and keeps round 1's plan: the same ~54-stage split for every item
+            uniform = None
+            if self.precision == 'bf16x3':
+                S = max(1, (P_pad + 1727) // 1728)
+                uniform = {w: S for w in planlib.WgradProgram.CLASS_COST_US}
+            prog = planlib.balanced_program(build, self.mp, P_pad, splits=uniform)
             rules_dev = torch.from_numpy(prog.rules_bytes()).to(self.device)
             wg_map = torch.from_numpy(prog.wg_map()).to(self.device)
             # the item table holds offsets, not addresses: one host-to-device copy per (network, point count), ever
