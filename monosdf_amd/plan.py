@@ -316,6 +316,7 @@ class WgradProgram:
     # networks (`target` sweeps; profiles/r04_wgrad_splits.md: rms error 3 % for workgroups of <= 500 us)
     CLASS_COST_US = {1.0: (8.4, 6.0), 0.6: (5.2, 6.0), 0.5: (4.1, 5.0), 0.3: (3.0, 8.0), 0.2: (2.2, 6.0),
                      0.0: (1.45, 2.0)}
+    CORUN_SLOWDOWN = {0.5: 1.45, 0.6: 1.45}
     N_CU = 256
     REDUCE_US_PER_MB = 0.54          # msdf_reduce_k reads the partial blocks at ~1.85 TB/s
 
@@ -422,7 +423,10 @@ def choose_splits(classes, n_stages, part_floats, target_us=None):
     top = max(classes)
     best = None
     # workgroups longer than ~500 us are outside what the model was fitted on (and measured 10-20 % slower than it says:
-    # the narrow classes are latency-bound when they run beside wide workgroups instead of beside each other)
+    # the narrow classes are latency-bound when they run for that long beside wide workgroups).  Inside that range the
+    # model ranks plans as the GPU does -- a same-process sweep of the wide split count (scripts/bench_wgrad.py fine,
+    # profiles/r04_wgrad_splits.md): the cliffs where the wide workgroups spill into one more round of the 256 CUs and
+    # the best plan of each of the three networks are where it puts them
     tau_top, t0_top = cost[top]
     if target_us is None:
         # every split count of the widest class whose workgroups last 100 ... 500 us, each with its own duration as D
@@ -439,11 +443,18 @@ def choose_splits(classes, n_stages, part_floats, target_us=None):
             S[c] = int(min(n_stages, max(1, math.ceil(n_stages * tau / max(d - t0, tau)))))
             part += part_floats.get(c, 0) * S[c]
         t = 0.0
-        for slow in (1.0, 1.3):        # the narrow classes as calibrated, and 30 % slower: pick what is good in both cases
+        for corun in (False, True):
+            # as calibrated, and with the 96- / 128-column classes at the per-stage time they measure while they run
+            # BESIDE wide workgroups (6 us instead of 4.1: a plan of the network behind the hash grid whose wide
+            # workgroups fill 0.7 of a round, with the 80-column workgroups on the other CUs from the start, measured
+            # 0.59-0.63 ms where the model said 0.50; the 48-column and thin classes show no such effect): a plan has
+            # to be good either way
             durs = []
             for c, n_items in classes.items():
                 tau, t0 = cost[c]
-                durs += [t0 + (tau if c == top else slow * tau) * -(-n_stages // S[c])] * (n_items * S[c])
+                if corun and c in WgradProgram.CORUN_SLOWDOWN:
+                    tau *= WgradProgram.CORUN_SLOWDOWN[c]
+                durs += [t0 + tau * -(-n_stages // S[c])] * (n_items * S[c])
             durs.sort(reverse=True)
             t = max(t, _makespan_us(durs, WgradProgram.N_CU))
         t += WgradProgram.REDUCE_US_PER_MB * 4e-6 * part

@@ -116,3 +116,27 @@ if 'target' in sys.argv[2:]:
         run(pr, 'target %4d us %s' % (D, sorted(set((it['weight'], it['n_splits']) for it in pr.items))), iters=8)
 if 'calib' in sys.argv[2:]:
     calibrate()
+
+
+def fine():
+    """Same process, interleaved repetitions: the chooser's plan against plans with the wide class pinned to a range of
+    split counts (the other classes by the chooser's rule for that workgroup duration)."""
+    import numpy as np
+    cost = planlib.WgradProgram.CLASS_COST_US
+    n_stages = P_pad // 32
+    rng = {'mlp': range(54, 76), 'grid': list(range(76, 92)) + list(range(106, 118)), 'color': range(70, 100)}[which]
+    progs = [('library', planlib.balanced_program(build, mp, P_pad))]
+    for sw in rng:
+        D = cost[1.0][1] + cost[1.0][0] * -(-n_stages // sw)
+        progs.append(('wide %d' % sw, planlib.balanced_program(build, mp, P_pad, target_us=D)))
+    res = {n: [] for n, _ in progs}
+    for rep in range(3):
+        for n, pr in progs:
+            res[n].append(run(pr, '%s %s' % (n, sorted(set((it['weight'], it['n_splits']) for it in pr.items))), iters=6))
+    print('--- median of 3 ---')
+    for n, _ in progs:
+        print('%-12s %.3f ms' % (n, float(np.median(res[n]))))
+
+
+if 'fine' in sys.argv[2:]:
+    fine()
