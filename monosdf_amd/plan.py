@@ -397,6 +397,13 @@ def _makespan_us(durations, n_cu):
 
 
 _SPLIT_CACHE = {}
+# the second evaluation of a candidate plan slows EVERY class but the widest by 30 % (0 switches that off: comparison
+# runs).  Stand-alone the colour network's launch is faster without it (0.27 against 0.33 ms: 96 instead of 77 splits of
+# its wide items, 314 workgroups), but inside the training step -- where that launch runs beside the scatter and the
+# SDF launch -- the plan that fits ONE round of the 256 CUs measured better: configs[2] 3.37 against 3.39 ms per step
+# (three runs each on one box), configs[1] the same
+import os as _os
+_ALL_NARROW_SLOW = _os.environ.get('MSDF_WGRAD_ALL_NARROW_SLOW', '1') != '0'
 
 
 def model_launch_us(prog):
@@ -454,6 +461,8 @@ def choose_splits(classes, n_stages, part_floats, target_us=None):
                 tau, t0 = cost[c]
                 if corun and c in WgradProgram.CORUN_SLOWDOWN:
                     tau *= WgradProgram.CORUN_SLOWDOWN[c]
+                elif corun and c != top and _ALL_NARROW_SLOW:
+                    tau *= 1.3
                 durs += [t0 + tau * -(-n_stages // S[c])] * (n_items * S[c])
             durs.sort(reverse=True)
             t = max(t, _makespan_us(durs, WgradProgram.N_CU))
