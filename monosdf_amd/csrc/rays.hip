@@ -51,7 +51,7 @@ struct PixelRaysArgs {
   const int* frame_list;     // [n_frames] index into pose / intrinsics / images, or NULL (identity)
   const float* pose;         // [N,4,4]
   const float* K;            // [N,4,4]
-  int n, width, hw;
+  int n, width, hw, n_frames;
   float* dirs;               // [n,3]
   float* dirs_cam;           // [n,3]
   float* cam_loc;            // [n,3]
@@ -66,6 +66,19 @@ __global__ void __launch_bounds__(256) msdf_pixel_rays_k(const PixelRaysArgs a) 
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n) return;
   const long long id = a.idx[i];
+  if (id < 0 || id >= (long long)a.n_frames * a.hw) {
+    // an index outside the table: no memory is touched for it; the ray comes back as zeros with frame position -1
+#pragma unroll
+    for (int r = 0; r < 3; ++r) a.dirs[3 * i + r] = a.dirs_cam[3 * i + r] = a.cam_loc[3 * i + r] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a.ray_pose[16 * (size_t)i + k] = 0.f;
+    a.frame_pos[i] = -1;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (a.src[t] != nullptr)
+        for (int c = 0; c < a.ch[t]; ++c) a.dst[t][(size_t)i * a.ch[t] + c] = 0.f;
+    return;
+  }
   const int f = (int)(id / a.hw), pix = (int)(id - (long long)f * a.hw);
   const int frame = a.frame_list ? a.frame_list[f] : f;
   // the reference's uv grid (scene_dataset.py:258-260): pixel p of a row-major image -> (u, v) = (column, row)
@@ -125,7 +138,7 @@ extern "C" int msdf_pixel_rays(const int64_t* ray_idx, int n, const int32_t* fra
     return MSDF_ERR_ARG;
   PixelRaysArgs a;
   a.idx = (const long long*)ray_idx; a.frame_list = frame_list; a.pose = pose_all; a.K = intrinsics_all;
-  a.n = n; a.width = width; a.hw = hw;
+  a.n = n; a.width = width; a.hw = hw; a.n_frames = n_frames;
   a.dirs = ray_dirs; a.dirs_cam = ray_dirs_cam; a.cam_loc = cam_loc; a.ray_pose = ray_pose; a.frame_pos = frame_pos;
   for (int t = 0; t < 4; ++t) {
     a.src[t] = nullptr; a.dst[t] = nullptr; a.ch[t] = 0;

@@ -65,6 +65,11 @@ def test_pixel_batches_on_the_device_match_the_reference(errlog):
     assert ind.shape == (0,) and smp['ray_dirs'].shape == (0, 3) and smp['ray_pose'].shape == (0, 4, 4) and g == {}
     ind, smp, g = bare.batch(torch.tensor([0, len(bare) - 1]).cuda())
     assert ind.tolist() == [0, spec['n_images'] - 1] and g == {}
+    # an index outside the table touches no memory: zeros and frame position -1
+    ind, smp, g = tab.batch(torch.tensor([len(tab), -1, 5]).cuda())
+    assert ind.tolist()[:2] == [-1, -1] and ind.tolist()[2] == 0
+    assert float(smp['ray_dirs'][:2].abs().max()) == 0.0 and float(g['rgb'][:2].abs().max()) == 0.0
+    assert float(smp['ray_dirs'][2].norm()) > 0.99
 
 
 @pytest.mark.gpu
