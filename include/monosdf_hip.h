@@ -448,7 +448,8 @@ int msdf_camera_rays(const float* uv, const float* pose, const float* intrinsics
  * (scene_dataset.py:258-260).  Outputs: ray_dirs, ray_dirs_cam (the reference's ray_dirs_tmp), cam_loc [n,3],
  * ray_pose [n,16], frame_pos [n] int32 (= ray_idx / hw, the reference's ray_frame_idx).  Ground truth: up to 4 image
  * stacks gt_src[k] [n_frames * hw, gt_channels[k]] (rows in frame-list order, device pointers; the arrays of pointers
- * themselves are HOST arrays) gathered into gt_dst[k] [n, gt_channels[k]]; a NULL gt_src[k] is skipped. */
+ * themselves are HOST arrays) gathered into gt_dst[k] [n, gt_channels[k]]; a NULL gt_src[k] is skipped.  An index outside
+ * [0, n_frames * hw) touches no memory: its outputs are zeros and its frame_pos is -1. */
 int msdf_pixel_rays(const int64_t* ray_idx, int n, const int32_t* frame_list, int n_frames, const float* pose_all,
                     const float* intrinsics_all, int width, int hw, float* ray_dirs, float* ray_dirs_cam,
                     float* cam_loc, float* ray_pose, int32_t* frame_pos, const float* const* gt_src,
