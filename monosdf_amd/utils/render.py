@@ -8,6 +8,8 @@
   one call of the no-grad forward kernel on the GPU (the reference moves 100k-point chunks to the CPU).
   Marching cubes itself (skimage, plots.py:199) stays with the caller.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -48,6 +50,16 @@ def lin2img(tensor, img_res):
 
 
 _WIDTH = {'rgb_values': 3, 'normal_map': 3, 'depth_values': 1}
+# streams the chunks of render_image alternate over (1: the reference's sequential loop)
+RENDER_STREAMS = int(os.environ.get('MSDF_RENDER_STREAMS', '2'))
+_STREAMS = {}
+
+
+def _render_streams(device, n):
+    key = (torch.device(device).index, n)
+    if key not in _STREAMS:
+        _STREAMS[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+    return _STREAMS[key]
 
 
 @torch.no_grad()
@@ -61,9 +73,29 @@ def render_image(model, model_input, indices, total_pixels, split_n_pixels=1024,
         chunks = split_input(model_input, total_pixels, split_n_pixels)
         world, rank = parallel.world(), parallel.rank()
         rows = []
-        for c in range(rank, len(chunks), world):
-            out = model(chunks[c], indices)
-            rows.append(torch.cat([out[k].reshape(out[k].shape[0], -1) for k in keys], 1))
+        mine = list(range(rank, len(chunks), world))
+        dev = model_input['uv'].device
+        if dev.type == 'cuda' and len(mine) > 1 and RENDER_STREAMS > 1:
+            # chunks are independent: consecutive chunks go to alternating streams, so that the partly filled last round
+            # of workgroups of one chunk's kernels (1,024 rays x 98 samples = 3.06 / 3.19 rounds of the 512 slots) and
+            # the launch gaps of its small kernels are filled by the other chunk's work.  Same kernels, same values.
+            main = torch.cuda.current_stream(dev)
+            streams = _render_streams(dev, RENDER_STREAMS)
+            for st in streams:
+                st.wait_stream(main)
+            for j, c in enumerate(mine):
+                st = streams[j % len(streams)]
+                with torch.cuda.stream(st):
+                    out = model(chunks[c], indices)
+                    r = torch.cat([out[k].reshape(out[k].shape[0], -1) for k in keys], 1)
+                r.record_stream(main)              # allocated on `st`, read by the concatenation on `main`
+                rows.append(r)
+            for st in streams:
+                main.wait_stream(st)
+        else:
+            for c in mine:
+                out = model(chunks[c], indices)
+                rows.append(torch.cat([out[k].reshape(out[k].shape[0], -1) for k in keys], 1))
         width = sum(_WIDTH[k] for k in keys)
         local = torch.cat(rows, 0) if rows else torch.zeros(0, width, device=model_input['uv'].device)
         if world > 1:
