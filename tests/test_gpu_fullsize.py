@@ -341,7 +341,11 @@ def test_fullsize_sdf_volume_512():
         t0 = time.time()
         blocks = list(render.sdf_volume(fn, resolution=512, grid_boundary=(-1.1, 1.1), shard=False))
         torch.cuda.synchronize()
-        dt = time.time() - t0
+        dt_first = time.time() - t0           # includes the one-off allocation of the 537 MB pinned buffer
+        t0 = time.time()
+        blocks = list(render.sdf_volume(fn, resolution=512, grid_boundary=(-1.1, 1.1), shard=False))
+        torch.cuda.synchronize()
+        dt = time.time() - t0                 # what every further block costs (resolution 1024 = 8 such blocks)
     assert len(blocks) == 1
     origin, spacing, vol = blocks[0]
     assert vol.shape == (512, 512, 512) and np.isfinite(vol).all()
@@ -362,7 +366,7 @@ def test_fullsize_sdf_volume_512():
     far_block = vol[:8, :8, :8]
     assert np.all(far_block == far_block[0, 0, 0])
     _record('configs[4] 512^3 SDF volume, coarse-to-fine, one GPU',
-            {'seconds': dt, 'voxels': n ** 3, 'fraction_refined_to_finest_level': frac})
+            {'seconds': dt, 'seconds_first_call': dt_first, 'voxels': n ** 3, 'fraction_refined_to_finest_level': frac})
 
 
 def test_first_form_of_the_binned_scatter_still_runs():
