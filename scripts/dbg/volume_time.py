@@ -6,7 +6,8 @@ import bench
 from monosdf_amd.model.network import MonoSDFNetwork
 torch.manual_seed(0)
 model = MonoSDFNetwork(bench.model_conf()).cuda().eval()
-fn = lambda p: model.implicit_network(p)[:, 0]
+import sys as _s
+fn = (lambda p: model.implicit_network.raw_sdf(p)) if 'raw' in _s.argv[1:] else (lambda p: model.implicit_network(p)[:, 0])
 with torch.no_grad():
     fn(torch.zeros(64, 3, device='cuda'))
     for rep in range(3):

@@ -346,6 +346,16 @@ def test_fullsize_sdf_volume_512():
         blocks = list(render.sdf_volume(fn, resolution=512, grid_boundary=(-1.1, 1.1), shard=False))
         torch.cuda.synchronize()
         dt = time.time() - t0                 # what every further block costs (resolution 1024 = 8 such blocks)
+        # the same volume from implicit_network.raw_sdf (column 0 alone: no features, no gradient)
+        raw = lambda p: model.implicit_network.raw_sdf(p)
+        t0 = time.time()
+        (_, _, vol_raw), = list(render.sdf_volume(raw, resolution=512, grid_boundary=(-1.1, 1.1), shard=False))
+        torch.cuda.synchronize()
+        dt_raw = time.time() - t0
+    # column 0 of the fused forward and the sdf-only kernel: the same network values (a voxel next to a refinement
+    # threshold may still be refined by one and not the other: those are left out)
+    diff = np.abs(vol_raw - blocks[0][2])
+    assert float((diff > 1e-5).mean()) < 1e-3, float((diff > 1e-5).mean())          # |sdf| <= 2: a few ulp, plus threshold voxels
     assert len(blocks) == 1
     origin, spacing, vol = blocks[0]
     assert vol.shape == (512, 512, 512) and np.isfinite(vol).all()
@@ -366,7 +376,8 @@ def test_fullsize_sdf_volume_512():
     far_block = vol[:8, :8, :8]
     assert np.all(far_block == far_block[0, 0, 0])
     _record('configs[4] 512^3 SDF volume, coarse-to-fine, one GPU',
-            {'seconds': dt, 'seconds_first_call': dt_first, 'voxels': n ** 3, 'fraction_refined_to_finest_level': frac})
+            {'seconds': dt, 'seconds_first_call': dt_first, 'seconds_with_raw_sdf': dt_raw, 'voxels': n ** 3,
+             'fraction_refined_to_finest_level': frac})
 
 
 def test_first_form_of_the_binned_scatter_still_runs():
