@@ -843,6 +843,23 @@ hb2_place_k(const float* __restrict__ grad, const float* __restrict__ grad2, con
   }
   __syncthreads();
 
+  // the gradient values of this thread's points are needed in phase 3 only, but they come from tensors the SDF kernels
+  // wrote long before (cold: HBM latency): issued here, they arrive under phases 1 and 2
+  float g1v[HB_PTS][C], g2v[HB_PTS][C], ggv[HB_PTS][3];
+#pragma unroll
+  for (int p = 0; p < HB_PTS; ++p) {
+    const uint32_t b = (blockIdx.x * HB_PTS + p) * HB_THREADS + tid;
+    const uint32_t bc = b < B ? b : B - 1;
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) {
+      const size_t gi = pitch ? (size_t)bc * pitch + level * C + ch : ((size_t)level * B + bc) * C + ch;
+      g1v[p][ch] = grad[gi];
+      g2v[p][ch] = (MODE == 2) ? grad2[gi] : 0.f;
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) ggv[p][d] = (MODE != 0) ? gg_inputs[(size_t)bc * 3 + d] : 0.f;
+  }
+
   // ---- phase 1: runs of equal cells, rank of every run head's corners inside (workgroup, slice) ----
   uint32_t rank2[HB_PTS][4];                 // two 13-bit ranks per word
   uint32_t rid[HB_PTS];                      // run id inside the 16-lane row (>= 1), 255 = no contribution
@@ -916,16 +933,15 @@ hb2_place_k(const float* __restrict__ grad, const float* __restrict__ grad2, con
     const float wx[2] = {1.f - c.sx, c.sx}, wy[2] = {1.f - c.sy, c.sy}, wz[2] = {1.f - c.sz, c.sz};
     float q0 = 0.f, q1 = 0.f, q2 = 0.f;
     if (MODE != 0) {
-      q0 = gg_inputs[(size_t)bc * 3 + 0] * c.dx * c.scale;
-      q1 = gg_inputs[(size_t)bc * 3 + 1] * c.dy * c.scale;
-      q2 = gg_inputs[(size_t)bc * 3 + 2] * c.dz * c.scale;
+      q0 = ggv[p][0] * c.dx * c.scale;
+      q1 = ggv[p][1] * c.dy * c.scale;
+      q2 = ggv[p][2] * c.dz * c.scale;
     }
     float g1[C], g2[C];
 #pragma unroll
     for (int ch = 0; ch < C; ++ch) {
-      const size_t gi = pitch ? (size_t)bc * pitch + level * C + ch : ((size_t)level * B + bc) * C + ch;
-      g1[ch] = live ? grad[gi] : 0.f;
-      g2[ch] = (MODE == 2 && live) ? grad2[gi] : 0.f;
+      g1[ch] = live ? g1v[p][ch] : 0.f;
+      g2[ch] = (MODE == 2 && live) ? g2v[p][ch] : 0.f;
     }
     const bool head = (heads >> p) & 1u;
 #pragma unroll
